@@ -1,0 +1,94 @@
+"""CPU oracle for batching/indexing.  TEST INFRASTRUCTURE ONLY.
+
+Restates `BPEMolDataset.process_step2` (`src/data/bpe_dataset.py:56-84`) and
+`process_step3` (`:87-155`) in plain Python/numpy.  Integer work: results must
+be bit-exact.  Parity status: PINNED by `tests/golden/collate_*.pt`, which hold
+the reference functions' own outputs (made by `tools/make_fixtures.py`).
+
+The negative-pair sampler draws from Python's module-level `random.random()`
+exactly where the reference does: once for every ordered atom pair that lies in
+two different pieces and is NOT bonded, in (graph, row, column) order (`:127-132`).
+"""
+import random
+
+import numpy as np
+import torch
+
+NONE_BOND = 0        # index of `None` in the bond list (`src/utils/chem_utils.py:15`)
+NUM_BOND_TYPES = 4
+ATOM_PAD = 10        # `<pad>` follows the 10 real atoms (`src/utils/chem_utils.py:14,21-25`)
+NEG_RATE = 0.022     # `src/data/bpe_dataset.py:129`
+
+
+def to_matrix_form(mol):
+    """`process_step2`: dense bond-type matrix, per-atom piece id / position,
+    and the cross-piece mask (1 = atoms in different pieces)."""
+    n = len(mol['x'])
+    ad = np.full((n, n), NONE_BOND, dtype=np.int64)
+    for (a, b), t in zip(mol['edge_index'], mol['edge_attr']):
+        ad[a, b] = ad[b, a] = t
+    cross = np.ones((n, n), dtype=np.int64)
+    x_piece = np.zeros(n, dtype=np.int64)
+    x_pos = np.zeros(n, dtype=np.int64)
+    for pos, group in enumerate(mol['groups']):
+        if len(group):
+            g = np.asarray(group, dtype=np.int64)
+            cross[np.ix_(g, g)] = 0
+            x_piece[g] = mol['pieces'][pos]
+            x_pos[g] = pos
+    return {'x': list(mol['x']), 'ad_mat': ad.tolist(), 'props': mol['props'],
+            'pieces': mol['pieces'], 'x_pieces': x_piece.tolist(), 'x_pos': x_pos.tolist(),
+            'edge_select': cross.tolist()}
+
+
+def collate(mols2, piece_pad, rng=random):
+    """`process_step3` on a list of `to_matrix_form` results.  `piece_pad` is
+    the tokenizer's pad index (= vocabulary size)."""
+    B = len(mols2)
+    lens = [len(m['x']) for m in mols2]
+    N = max(lens)
+    x = np.full((B, N), ATOM_PAD, dtype=np.int64)
+    xp = np.full((B, N), piece_pad, dtype=np.int64)
+    xq = np.zeros((B, N), dtype=np.int64)
+    mask = np.ones((B, N), dtype=bool)
+    for i, m in enumerate(mols2):
+        k = lens[i]
+        x[i, :k], xp[i, :k], xq[i, :k] = m['x'], m['x_pieces'], m['x_pos']
+        mask[i, :k] = False
+    sel = np.zeros((B, N, N), dtype=bool)
+    e_src, e_dst, e_type, golden, in_piece = [], [], [], [], []
+    for i, m in enumerate(mols2):
+        ad, cross = m['ad_mat'], m['edge_select']
+        base = N * i
+        for a in range(lens[i]):
+            ad_row, cross_row = ad[a], cross[a]
+            for b in range(lens[i]):
+                t = ad_row[b]
+                c = cross_row[b]
+                if t != NONE_BOND:
+                    if c == 0:
+                        in_piece.append(len(e_src))
+                    e_src.append(a + base)
+                    e_dst.append(b + base)
+                    e_type.append(t)
+                if c == 1 and (t != NONE_BOND or rng.random() < NEG_RATE):
+                    sel[i, a, b] = True
+                    golden.append(t)
+    L = max(len(m['pieces']) for m in mols2)
+    pieces = np.full((B, L), piece_pad, dtype=np.int64)
+    for i, m in enumerate(mols2):
+        pieces[i, :len(m['pieces'])] = m['pieces']
+    onehot = np.zeros((len(e_type), NUM_BOND_TYPES), dtype=np.int64)
+    if e_type:
+        onehot[np.arange(len(e_type)), np.asarray(e_type)] = 1
+    edge_index = np.stack([np.asarray(e_src, dtype=np.int64), np.asarray(e_dst, dtype=np.int64)]) \
+        if e_src else np.zeros((2, 0), dtype=np.int64)
+    return {
+        'x': torch.from_numpy(x), 'x_pieces': torch.from_numpy(xp), 'x_pos': torch.from_numpy(xq),
+        'atom_mask': torch.from_numpy(mask), 'pieces': torch.from_numpy(pieces),
+        'edge_index': torch.from_numpy(edge_index), 'edge_attr': torch.from_numpy(onehot),
+        'edge_select': torch.from_numpy(sel),
+        'golden_edge': torch.tensor(golden, dtype=torch.long),
+        'in_piece_edge_idx': in_piece,
+        'props': torch.tensor([m['props'] for m in mols2]),
+    }

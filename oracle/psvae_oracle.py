@@ -1,0 +1,316 @@
+"""CPU oracle for the PS-VAE training step.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain PyTorch on the CPU, the arithmetic of the
+reference training step so that the HIP path can be checked against it.  Only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
+may import it; the product package never does.
+
+Parity status: PINNED.  `tools/make_fixtures.py` runs the reference's own
+modules (imported from the read-only reference tree, with inert stand-ins for
+the absent rdkit / pytorch_lightning / torch_geometric packages) on seeded
+inputs and stores their outputs under `tests/golden/`; `tests/test_oracle_golden.py`
+checks this restatement against those files.  The one piece of arithmetic that
+lives in an absent dependency is `torch_geometric.nn.GINEConv` (un-vendored,
+version unpinned by the reference); its published formula
+    out_i = nn( (1 + eps) * x_i + sum_{j -> i} relu(x_j + e_ji) )
+is restated in `gine_conv` below and in the stand-in the fixture script gives
+the reference, so that single formula is "parity unpinned" against PyG itself.
+
+Every function follows the reference lines cited in its docstring.  The batch
+is the reference's padded batch dict (`src/data/bpe_dataset.py:142-155`) and
+the parameters are a dict keyed by the reference's state-dict names, so the
+cost profile (padded rows, dense `[B,N,N,*]` pair tensors) is the reference's.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# sizes and parameter recipe
+# --------------------------------------------------------------------------
+def default_dims(vocab_size=300, **over):
+    """Layer sizes from the training CLI defaults (`src/train.py:92-110`,
+    `src/utils/nn_utils.py:180-206`, `src/utils/chem_utils.py:14-15`)."""
+    d = dict(num_piece=vocab_size + 2, num_atom=11, num_bond=4, max_pos=50,
+             d_atom=50, d_piece=100, d_pos=50, hidden=300, graph=400, latent=56,
+             rnn=200, pred_hidden=200, n_props=2, t_enc=4, t_dec=4)
+    d.update(over)
+    return d
+
+
+def param_shapes(d):
+    """State-dict names and shapes in the reference's registration order
+    (`src/pl_models/ps_vae_model.py:25-27` and the module constructors)."""
+    H, node = d['hidden'], d['d_atom'] + d['d_piece'] + d['d_pos']
+    pin = 2 * H + d['latent']
+    out = []
+
+    def lin(name, o, i):
+        out.append((name + '.weight', (o, i)))
+        out.append((name + '.bias', (o,)))
+
+    def enc(prefix, dim_out, t):
+        lin(prefix + 'node_trans', H, node)
+        lin(prefix + 'edge_trans', H, d['num_bond'])
+        out.append((prefix + 'conv.eps', (1,)))
+        lin(prefix + 'conv.nn.seq.0', H, H)
+        lin(prefix + 'conv.nn.seq.2', H, H)
+        lin(prefix + 'linear', dim_out, H * t)
+
+    lin('predictor.mlp.0', d['pred_hidden'], d['latent'])
+    lin('predictor.mlp.2', d['pred_hidden'], d['pred_hidden'])
+    lin('predictor.output', d['n_props'], d['pred_hidden'])
+    enc('encoder.', d['graph'], d['t_enc'])
+    out.append(('decoder.atom_embedding.weight', (d['num_atom'], d['d_atom'])))
+    out.append(('decoder.piece_embedding.weight', (d['num_piece'], d['d_piece'])))
+    out.append(('decoder.pos_embedding.weight', (d['max_pos'], d['d_pos'])))
+    lin('decoder.latent_to_rnn_hidden', d['rnn'], d['latent'])
+    out.append(('decoder.rnn.weight_ih_l0', (3 * d['rnn'], d['d_piece'])))
+    out.append(('decoder.rnn.weight_hh_l0', (3 * d['rnn'], d['rnn'])))
+    out.append(('decoder.rnn.bias_ih_l0', (3 * d['rnn'],)))
+    out.append(('decoder.rnn.bias_hh_l0', (3 * d['rnn'],)))
+    lin('decoder.to_vocab', d['num_piece'], d['rnn'])
+    enc('decoder.graph_embedding.', 1, d['t_dec'])
+    lin('decoder.edge_predictor.0.seq.0', pin // 2, pin)
+    lin('decoder.edge_predictor.0.seq.2', pin // 2, pin // 2)
+    lin('decoder.edge_predictor.0.seq.4', pin, pin // 2)
+    lin('decoder.edge_predictor.1', d['num_bond'], pin)
+    lin('decoder.W_mean', d['latent'], d['graph'])
+    lin('decoder.W_log_var', d['latent'], d['graph'])
+    return out
+
+
+BUFFER_SUFFIX = 'conv.eps'
+
+
+def make_params(d, seed=2021):
+    """Seeded random parameters (a recipe of this build, not the reference's
+    initialiser): weights U(-1/sqrt(fan_in), 1/sqrt(fan_in)), embedding tables
+    0.5*N(0,1), biases U(-0.1, 0.1), drawn from one CPU generator in state-dict
+    order, so every process regenerates the same values."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    sd = {}
+    for name, shape in param_shapes(d):
+        if name.endswith(BUFFER_SUFFIX):
+            sd[name] = torch.zeros(shape)
+        elif 'embedding.weight' in name:
+            sd[name] = 0.5 * torch.randn(shape, generator=g)
+        elif len(shape) == 2:
+            a = 1.0 / math.sqrt(shape[1])
+            sd[name] = torch.empty(shape).uniform_(-a, a, generator=g)
+        else:
+            sd[name] = torch.empty(shape).uniform_(-0.1, 0.1, generator=g)
+    return sd
+
+
+def trainable_names(d):
+    return [n for n, _ in param_shapes(d) if not n.endswith(BUFFER_SUFFIX)]
+
+
+# --------------------------------------------------------------------------
+# model arithmetic
+# --------------------------------------------------------------------------
+def gine_conv(x, src, dst, e, p, pre):
+    """One GINEConv application: message relu(x_src + e), sum at dst, then the
+    2-layer MLP on agg + (1+eps)*x  (`src/modules/encoder.py:48,58`;
+    `src/modules/common_nn.py:15-23`)."""
+    msg = torch.relu(x.index_select(0, src) + e)
+    agg = torch.zeros_like(x).index_add_(0, dst, msg)
+    h = agg + (1.0 + p[pre + 'conv.eps']) * x
+    h = torch.relu(F.linear(h, p[pre + 'conv.nn.seq.0.weight'], p[pre + 'conv.nn.seq.0.bias']))
+    return F.linear(h, p[pre + 'conv.nn.seq.2.weight'], p[pre + 'conv.nn.seq.2.bias'])
+
+
+def embed_node(x, edge_index, edge_attr_onehot, p, pre, t):
+    """`Encoder.embed_node` (`src/modules/encoder.py:53-61`)."""
+    h = F.linear(x.float(), p[pre + 'node_trans.weight'], p[pre + 'node_trans.bias'])
+    e = F.linear(edge_attr_onehot.float(), p[pre + 'edge_trans.weight'], p[pre + 'edge_trans.bias'])
+    src, dst = edge_index[0], edge_index[1]
+    layers = [h]
+    for _ in range(t):
+        h = gine_conv(h, src, dst, e, p, pre)
+        layers.append(h)
+    return layers  # [h0, x1 .. xt]
+
+
+def embed_graph(all_x, graph_ids, node_mask, p, pre):
+    """`Encoder.embed_graph` (`src/modules/encoder.py:63-69`)."""
+    n_graph = int(graph_ids[-1]) + 1
+    pooled = torch.zeros(n_graph, all_x.shape[-1])
+    keep = ~node_mask
+    pooled.index_add_(0, graph_ids[keep], all_x[keep])
+    return pooled, F.linear(pooled, p[pre + 'linear.weight'], p[pre + 'linear.bias'])
+
+
+def gru_sequence(x_seq, h0, p):
+    """Single-layer batch-first GRU, gate order (r, z, n) as `torch.nn.GRU`
+    stores it (`src/modules/vae_piece_decoder.py:29,89`)."""
+    w_ih, w_hh = p['decoder.rnn.weight_ih_l0'], p['decoder.rnn.weight_hh_l0']
+    b_ih, b_hh = p['decoder.rnn.bias_ih_l0'], p['decoder.rnn.bias_hh_l0']
+    R = h0.shape[-1]
+    h, outs = h0, []
+    for t in range(x_seq.shape[1]):
+        gi = F.linear(x_seq[:, t], w_ih, b_ih)
+        gh = F.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(gi[:, :R] + gh[:, :R])
+        u = torch.sigmoid(gi[:, R:2 * R] + gh[:, R:2 * R])
+        c = torch.tanh(gi[:, 2 * R:] + r * gh[:, 2 * R:])
+        h = (1.0 - u) * c + u * h
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def forward(p, d, batch, eps, keep=None):
+    """`PSVAEModel.forward` (`src/pl_models/ps_vae_model.py:33-58`) with the
+    decoder's `forward` (`src/modules/vae_piece_decoder.py:71-117`) inlined.
+    `eps` replaces the `randn_like` draw of `rsample` (:61).  Returns a dict of
+    the five losses; intermediate tensors are added to `keep` when given."""
+    A = keep if keep is not None else {}
+    x_ids, xp, xq = batch['x'], batch['x_pieces'], batch['x_pos']
+    B, N = x_ids.shape
+    # embed_atom (vae_piece_decoder.py:65-69)
+    x0 = torch.cat([p['decoder.atom_embedding.weight'][x_ids],
+                    p['decoder.piece_embedding.weight'][xp],
+                    p['decoder.pos_embedding.weight'][xq]], dim=-1)
+    A['x0'] = x0
+    node_dim = x0.shape[-1]
+    graph_ids = torch.repeat_interleave(torch.arange(B), N)
+    ei, ea = batch['edge_index'], batch['edge_attr']
+    enc_layers = embed_node(x0.view(-1, node_dim), ei, ea, p, 'encoder.', d['t_enc'])
+    A['enc_layers'] = enc_layers
+    all_x = torch.cat(enc_layers[1:], dim=-1)
+    pooled, cond = embed_graph(all_x, graph_ids, batch['atom_mask'].flatten(), p, 'encoder.')
+    A['pooled'], A['cond'] = pooled, cond
+    # rsample (vae_piece_decoder.py:56-63)
+    z_mean = F.linear(cond, p['decoder.W_mean.weight'], p['decoder.W_mean.bias'])
+    z_log_var = -torch.abs(F.linear(cond, p['decoder.W_log_var.weight'], p['decoder.W_log_var.bias']))
+    kl = -0.5 * torch.sum(1.0 + z_log_var - z_mean * z_mean - torch.exp(z_log_var)) / B
+    z = z_mean + torch.exp(z_log_var / 2) * eps
+    A['z_mean'], A['z_log_var'], A['z'] = z_mean, z_log_var, z
+    # piece branch (vae_piece_decoder.py:81-90)
+    pieces = batch['pieces']
+    gold_piece = pieces[:, 1:].flatten()
+    emb = p['decoder.piece_embedding.weight'][pieces]
+    h0 = F.linear(z, p['decoder.latent_to_rnn_hidden.weight'], p['decoder.latent_to_rnn_hidden.bias'])
+    rnn_out = gru_sequence(emb[:, :-1], h0, p)
+    logits = F.linear(rnn_out, p['decoder.to_vocab.weight'], p['decoder.to_vocab.bias'])
+    A['rnn_out'], A['logits'] = rnn_out, logits
+    # decoder graph branch over in-piece bonds (ps_vae_model.py:45-48; decoder :93-96)
+    idx = batch['in_piece_edge_idx']
+    idx_t = torch.tensor(idx, dtype=torch.long)
+    dec_layers = embed_node(x0.view(-1, node_dim), ei[:, idx_t], ea[idx_t], p,
+                            'decoder.graph_embedding.', d['t_dec'])
+    A['dec_layers'] = dec_layers
+    node_emb = dec_layers[-1].view(B, N, -1)
+    # pair inputs exactly as the reference builds them (:97-109)
+    sel = batch['edge_select']
+    src = torch.repeat_interleave(node_emb, N, dim=1).view(B, N, N, -1)[sel]
+    dst = torch.repeat_interleave(node_emb, N, dim=0).view(B, N, N, -1)[sel]
+    lat = torch.repeat_interleave(z, N * N, dim=0).view(B, N, N, -1)[sel]
+    pair_in = torch.cat([src, dst, lat], dim=-1)
+    A['pair_in'] = pair_in
+    h = pair_in
+    for k in (0, 2):
+        h = torch.relu(F.linear(h, p[f'decoder.edge_predictor.0.seq.{k}.weight'],
+                                p[f'decoder.edge_predictor.0.seq.{k}.bias']))
+    h = F.linear(h, p['decoder.edge_predictor.0.seq.4.weight'], p['decoder.edge_predictor.0.seq.4.bias'])
+    pair_logits = F.linear(h, p['decoder.edge_predictor.1.weight'], p['decoder.edge_predictor.1.bias'])
+    A['pair_logits'] = pair_logits
+    # losses (:53-54,113-117)
+    piece_loss = F.cross_entropy(logits.view(-1, logits.shape[-1]), gold_piece,
+                                 ignore_index=d['num_piece'] - 2)
+    edge_loss = F.cross_entropy(pair_logits, batch['golden_edge'])
+    # predictor + MSE (predictor.py:19-21; ps_vae_model.py:54-57)
+    q = torch.relu(F.linear(z, p['predictor.mlp.0.weight'], p['predictor.mlp.0.bias']))
+    q = torch.relu(F.linear(q, p['predictor.mlp.2.weight'], p['predictor.mlp.2.bias']))
+    pred = F.linear(q, p['predictor.output.weight'], p['predictor.output.bias'])
+    A['pred'] = pred
+    golden = batch['props'].reshape(B, -1)[:, batch.get('selected_properties', [0, 2])].float()
+    pred_loss = F.mse_loss(pred, golden)
+    return {'pred': pred_loss, 'rec': piece_loss + edge_loss, 'piece': piece_loss,
+            'edge': edge_loss, 'kl': kl}
+
+
+def accuracies(p, d, batch, eps):
+    """The `return_accu` branch (`src/modules/vae_piece_decoder.py:120-124`)."""
+    keep = {}
+    with torch.no_grad():
+        forward(p, d, batch, eps, keep)
+    logits = keep['logits'].view(-1, keep['logits'].shape[-1])
+    gold = batch['pieces'][:, 1:].flatten()
+    not_pad = gold != d['num_piece'] - 2
+    piece_accu = ((logits.argmax(-1) == gold) & not_pad).sum().item() / not_pad.sum().item()
+    edge_accu = (keep['pair_logits'].argmax(-1) == batch['golden_edge']).sum().item() / len(batch['golden_edge'])
+    return piece_accu, edge_accu
+
+
+def get_z_mean(p, d, batch):
+    """Encoder-only path of `PSVAEModel.get_z` (`ps_vae_model.py:160-170`),
+    returning the deterministic mean and log-variance instead of a sample."""
+    keep = {}
+    x_ids = batch['x']
+    B, N = x_ids.shape
+    x0 = torch.cat([p['decoder.atom_embedding.weight'][x_ids],
+                    p['decoder.piece_embedding.weight'][batch['x_pieces']],
+                    p['decoder.pos_embedding.weight'][batch['x_pos']]], dim=-1)
+    layers = embed_node(x0.view(B * N, -1), batch['edge_index'], batch['edge_attr'], p, 'encoder.', d['t_enc'])
+    graph_ids = torch.repeat_interleave(torch.arange(B), N)
+    _, cond = embed_graph(torch.cat(layers[1:], -1), graph_ids, batch['atom_mask'].flatten(), p, 'encoder.')
+    z_mean = F.linear(cond, p['decoder.W_mean.weight'], p['decoder.W_mean.bias'])
+    z_log_var = -torch.abs(F.linear(cond, p['decoder.W_log_var.weight'], p['decoder.W_log_var.bias']))
+    return z_mean, z_log_var
+
+
+def beta_at(step, cfg):
+    """`PSVAEModel.cal_beta` (`ps_vae_model.py:60-69`)."""
+    if step < cfg['kl_warmup']:
+        beta = 0
+    else:
+        beta = min(cfg['max_beta'], ((step - cfg['kl_warmup']) // cfg['kl_anneal_iter'] + 1) * cfg['step_beta'])
+    return beta + cfg['beta']
+
+
+TRAIN_CFG = dict(lr=1e-3, alpha=0.1, beta=0.0, max_beta=0.01, step_beta=0.002,
+                 kl_warmup=0, kl_anneal_iter=1000, grad_clip=10.0)
+
+
+def weighted_loss(losses, step, cfg=TRAIN_CFG):
+    """`PSVAEModel.weighted_loss` (`ps_vae_model.py:71-74`)."""
+    return cfg['alpha'] * losses['rec'] + (1 - cfg['alpha']) * losses['pred'] + beta_at(step, cfg) * losses['kl']
+
+
+class Trainer:
+    """Plain-loop equivalent of what Lightning drives for the reference:
+    forward, weighted loss, backward, `clip_grad_norm_(10)` (`src/train.py:47`)
+    and Adam(lr) (`ps_vae_model.py:123-127`).  Parameters that receive no
+    gradient (the decoder-side encoder's unused `linear`) are skipped by both,
+    as torch does for `grad is None`."""
+
+    def __init__(self, sd, d, cfg=TRAIN_CFG):
+        self.d, self.cfg = d, dict(cfg)
+        self.p = {k: v.clone() for k, v in sd.items()}
+        self.names = trainable_names(d)
+        for n in self.names:
+            self.p[n].requires_grad_(True)
+        self.opt = torch.optim.Adam([self.p[n] for n in self.names], lr=cfg['lr'])
+        self.step_idx = 0
+
+    def loss_and_grads(self, batch, eps):
+        for n in self.names:
+            self.p[n].grad = None
+        losses = forward(self.p, self.d, batch, eps)
+        total = weighted_loss(losses, self.step_idx, self.cfg)
+        total.backward()
+        return total, losses
+
+    def step(self, batch, eps, epoch=0):
+        total, losses = self.loss_and_grads(batch, eps)
+        params = [self.p[n] for n in self.names if self.p[n].grad is not None]
+        torch.nn.utils.clip_grad_norm_(params, self.cfg['grad_clip'])
+        for g in self.opt.param_groups:
+            g['lr'] = self.cfg['lr'] / (epoch + 1)
+        self.opt.step()
+        self.step_idx += 1
+        return float(total.detach()), {k: float(v.detach()) for k, v in losses.items()}
