@@ -1,0 +1,244 @@
+/*
+ * psvae.h - C ABI of libpsvae_hip.so: the PS-VAE encoder/decoder training step
+ * as hand-written gfx950 (MI355X) kernels.
+ *
+ * The reference has no FFI of its own: its hot path is the Python nn.Module
+ * surface of PS-VAE-main/src/modules/ (encoder, vae_piece_decoder, predictor, common_nn) and src/pl_models/ps_vae_model.py.
+ * Every entry point below therefore cites the reference function whose
+ * arithmetic it replaces; the Python package ps_vae_amd binds them with ctypes
+ * underneath modules that keep the reference's signatures.
+ *
+ * Conventions
+ *  - All device pointers are plain HIP device addresses (e.g. tensor.data_ptr()).
+ *    Float tensors are fp32, index tensors int32, row-major, contiguous unless a
+ *    leading dimension ("ld", in elements) is passed.
+ *  - The caller owns every buffer, including the workspace; the library
+ *    allocates no device memory and keeps no state between calls.
+ *  - Work is enqueued on the hipStream_t passed as `stream` (a void* here so the
+ *    header needs no HIP include); no entry point synchronises the device.
+ *  - Return value: 0 = success; negative = PSVAE_E_* argument error detected on
+ *    the host before anything was launched; positive = the hipError_t of a
+ *    failed launch.  psvae_strerror() describes either.
+ */
+#ifndef PSVAE_H
+#define PSVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSVAE_ABI_VERSION 1
+
+enum {
+    PSVAE_OK = 0,
+    PSVAE_E_NULL = -1,      /* a required pointer is NULL */
+    PSVAE_E_SHAPE = -2,     /* a size is negative / inconsistent / unsupported */
+    PSVAE_E_ALIGN = -3,     /* pointer or leading dimension breaks an alignment rule */
+    PSVAE_E_WORKSPACE = -4, /* workspace too small (see psvae_workspace_bytes) */
+    PSVAE_E_CAPACITY = -5   /* host output buffer too small */
+};
+
+const char* psvae_strerror(int code);
+int psvae_abi_version(void);
+
+/* ---- model sizes (src/utils/nn_utils.py:180-206, src/train.py:92-110) ---- */
+typedef struct psvae_dims {
+    int32_t num_piece;   /* V + 2  (Tokenizer.num_piece_type, src/data/mol_bpe.py:239) */
+    int32_t num_atom;    /* 11 */
+    int32_t num_bond;    /* 4; the kernels require exactly 4 */
+    int32_t max_pos;     /* rows of pos_embedding */
+    int32_t d_atom, d_piece, d_pos; /* embedding widths; node width = their sum */
+    int32_t hidden;      /* GINE hidden H (multiple of 4) */
+    int32_t graph;       /* encoder.linear output G */
+    int32_t latent;      /* Z */
+    int32_t rnn;         /* GRU hidden R */
+    int32_t pred_hidden;
+    int32_t n_props;
+    int32_t t_enc, t_dec; /* GINE iterations of encoder / decoder-side encoder */
+    int32_t pad_idx;     /* ignore_index of the piece loss (= V) */
+    float eps_enc, eps_dec; /* GINEConv eps buffers (conv.eps) */
+} psvae_dims;
+
+/* ---- parameters: one device pointer per state-dict entry ------------------
+ * Names in comments are the reference's state-dict keys.  The same struct type
+ * carries the gradient buffers (same shapes) for psvae_step_backward.
+ * Optional fast path: when enc_node_w/dec_node_w (and their biases) are
+ * adjacent in memory the two node_trans products run as one grouped launch;
+ * likewise W_mean/W_log_var.  Adjacency is detected, never required. */
+typedef struct psvae_params {
+    float *pred_w0, *pred_b0, *pred_w1, *pred_b1, *pred_wo, *pred_bo; /* predictor.mlp.{0,2}, predictor.output */
+    float *enc_node_w, *enc_node_b;   /* encoder.node_trans   [H, Din] */
+    float *enc_edge_w, *enc_edge_b;   /* encoder.edge_trans   [H, 4]   */
+    float *enc_w1, *enc_b1, *enc_w2, *enc_b2; /* encoder.conv.nn.seq.{0,2} [H,H] */
+    float *enc_lin_w, *enc_lin_b;     /* encoder.linear [G, t_enc*H] */
+    float *atom_emb, *piece_emb, *pos_emb; /* decoder.{atom,piece,pos}_embedding.weight */
+    float *l2h_w, *l2h_b;             /* decoder.latent_to_rnn_hidden [R, Z] */
+    float *gru_wih, *gru_whh, *gru_bih, *gru_bhh; /* decoder.rnn.*_l0 ([3R,Dp],[3R,R],[3R],[3R]) */
+    float *vocab_w, *vocab_b;         /* decoder.to_vocab [V+2, R] */
+    float *dec_node_w, *dec_node_b, *dec_edge_w, *dec_edge_b; /* decoder.graph_embedding.* */
+    float *dec_w1, *dec_b1, *dec_w2, *dec_b2;
+    float *sc_w0, *sc_b0, *sc_w1, *sc_b1, *sc_w2, *sc_b2; /* decoder.edge_predictor.0.seq.{0,2,4} */
+    float *sc_w3, *sc_b3;             /* decoder.edge_predictor.1 [4, 2H+Z] */
+    float *mean_w, *mean_b, *lvar_w, *lvar_b; /* decoder.W_mean / W_log_var [Z, G] */
+} psvae_params;
+
+/* ---- one packed batch ------------------------------------------------------
+ * Packed layout: the n real atoms of the batch, graph after graph (padding rows
+ * of the reference's [B,N] layout carry no edges, are masked out of pooling and
+ * are never selected as pairs, so dropping them is exact).  Built on the host by
+ * psvae_pack_batch from the index arrays of process_step3
+ * (src/data/bpe_dataset.py:87-155). */
+typedef struct psvae_batch {
+    int32_t B, n, E, E_in, S, L; /* graphs, atoms, directed bonds, in-piece bonds, selected pairs, padded sequence length */
+    const int32_t *atom_id, *piece_id, *pos_id; /* [n] */
+    const int32_t *node_graph;   /* [n]   graph of each atom */
+    const int32_t *graph_off;    /* [B+1] first atom of each graph */
+    /* full bond graph: CSR by target (rows = target, entries = sources in edge order) and by source */
+    const int32_t *rowptr, *col, *etype;       /* [n+1], [E], [E] */
+    const int32_t *rowptr_t, *col_t, *etype_t; /* transpose */
+    /* in-piece bond graph (edge_index[:, in_piece_edge_idx], src/pl_models/ps_vae_model.py:45-48) */
+    const int32_t *in_rowptr, *in_col, *in_etype;
+    const int32_t *in_rowptr_t, *in_col_t, *in_etype_t;
+    /* selected ordered atom pairs in row-major (graph, m, n) order = order of golden_edge */
+    const int32_t *pair_src, *pair_dst, *pair_graph, *pair_gold; /* [S] */
+    const int32_t *pair_by_src_ptr, *pair_by_src_idx; /* [n+1], [S] pairs grouped by src atom */
+    const int32_t *pair_by_dst_ptr, *pair_by_dst_idx; /* [n+1], [S] */
+    const int32_t *pair_graph_off;                    /* [B+1] */
+    const int32_t *pieces;       /* [B, L] piece ids incl. leading/trailing <s>, padded with pad_idx */
+    /* inverse lists for the deterministic embedding-table gradients */
+    const int32_t *atom_rows_ptr, *atom_rows_idx;   /* [num_atom+1], [n] atoms using each table row */
+    const int32_t *piece_rows_ptr, *piece_rows_idx; /* [num_piece+1], [n] */
+    const int32_t *pos_rows_ptr, *pos_rows_idx;     /* [max_pos+1], [n] */
+    const int32_t *seq_rows_ptr, *seq_rows_idx;     /* [num_piece+1], [B*(L-1)] GRU input tokens per table row */
+    const float *props;          /* [B, n_props] the selected property targets */
+    const float *eps;            /* [B, Z] the N(0,1) draw of rsample */
+    const float *denoms;         /* [4] loss denominators: non-pad target tokens, S, B, B*n_props.
+                                    Data-parallel callers all-reduce these so every rank
+                                    divides by the global-batch counts. */
+} psvae_batch;
+
+/* ---- whole training step ---------------------------------------------------
+ * psvae_step_forward  = PSVAEModel.forward (src/pl_models/ps_vae_model.py:33-58)
+ *   incl. VAEPieceDecoder.forward (src/modules/vae_piece_decoder.py:71-117),
+ *   Encoder.embed_node/embed_graph (src/modules/encoder.py:53-69), Predictor.forward
+ *   (src/modules/predictor.py:19-21).  losses[0..4] = pred, rec, piece, edge, kl.
+ * psvae_step_backward = what autograd derives from it; loss_grads[0..3] are the
+ *   upstream gradients of (pred, piece, edge, kl) as DEVICE floats (rec's
+ *   gradient is added to piece and edge by the caller).  Gradients are written
+ *   (not accumulated) into `grads`.  The two unused parameters of the
+ *   decoder-side encoder (its `linear`) have no field and get no gradient.
+ * The workspace holds the saved activations: pass the same buffer, dims and
+ * batch to forward and backward. */
+size_t psvae_workspace_bytes(const psvae_dims* dims, const psvae_batch* batch_sizes);
+int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                       void* workspace, size_t workspace_bytes, float* losses, void* stream);
+int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                        void* workspace, size_t workspace_bytes, const float* loss_grads,
+                        const psvae_params* grads, void* stream);
+/* Offsets (in floats) of named activations inside the workspace, for tests and
+ * the module-level API.  Returns -1 for an unknown name. */
+int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_batch* batch_sizes, const char* name);
+
+/* Encoder-only latent encoding = PSVAEModel.get_z (ps_vae_model.py:160-170)
+ * without the sampling: writes mean and log-variance [B, Z] each. */
+int psvae_encode(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                 void* workspace, size_t workspace_bytes, float* z_mean, float* z_log_var, void* stream);
+
+/* ---- optimiser: clip_grad_norm_(10) + Adam (src/train.py:47; ps_vae_model.py:123-127)
+ * over flat fp32 buffers of `count` elements.  `partials` is scratch of
+ * psvae_adam_partials(count) floats; grad_norm_out (device, may be NULL) gets
+ * the pre-clip L2 norm.  bias1/bias2 = 1-beta1^t, 1-beta2^t. */
+size_t psvae_adam_partials(int64_t count);
+int psvae_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                    float* partials, float max_norm, float lr, float beta1, float beta2, float adam_eps,
+                    float bias1, float bias2, float* grad_norm_out, void* stream);
+
+/* ---- single operators (same kernels as the step; used by the module-level API
+ * and the per-layer parity tests) -------------------------------------------- */
+/* nn.Linear (+ReLU) forward: y[M,N] = act(x[M,K] w[N,K]^T + b). src/modules/common_nn.py:15-23 */
+int psvae_linear_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                         int M, int N, int K, int relu, void* scratch, size_t scratch_bytes, void* stream);
+/* dx[M,K] = (dy[M,N] w[N,K]) * (mask > 0 if mask) ; accumulate adds into dx */
+int psvae_linear_backward_input(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                int M, int N, int K, const float* mask, int ldmask, int accumulate, void* stream);
+/* dw[N,K] = sum over nseg segments of dy_s^T x_s, db[N] = column sums of dy (db may be NULL) */
+int psvae_linear_backward_weight(const float* dy, int lddy, int64_t seg_stride_dy, const float* x, int ldx,
+                                 int64_t seg_stride_x, int nseg, float* dw, float* db, int M, int N, int K,
+                                 void* scratch, size_t scratch_bytes, void* stream);
+size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg);
+/* GINEConv message + aggregation (torch_geometric GINEConv as used at src/modules/encoder.py:48,58):
+ * out[i] = (1+eps) x[i] + sum_{e in row i} relu(x[col[e]] + edge_w[:,etype[e]] + edge_b) */
+int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
+                                 const int32_t* etype, const float* edge_w, const float* edge_b, float one_plus_eps,
+                                 float* out, int ldo, int n, int H, void* stream);
+/* dx[j] = (1+eps) da[j] + sum_{e in rowT j} da[colT[e]] * (x[j] + edge(etypeT[e]) > 0)  (+ pooled-gradient broadcast) */
+int psvae_gine_aggregate_backward(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr_t,
+                                  const int32_t* col_t, const int32_t* etype_t, const float* edge_w,
+                                  const float* edge_b, float one_plus_eps, const float* dpool, int ldp,
+                                  const int32_t* node_graph, float* dx, int lddx, int n, int H, void* stream);
+/* Gradient of edge_trans from one GINE application: d_edge_w[H,4], d_edge_b[H] from da (dL/d aggregated
+ * output), the layer input x and the by-target CSR.  `partial` is scratch of psvae_gine_edge_grad_scratch(n, H) floats. */
+size_t psvae_gine_edge_grad_scratch(int n, int H);
+int psvae_gine_edge_grad(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
+                         const int32_t* etype, const float* edge_w, const float* edge_b, float* d_edge_w,
+                         float* d_edge_b, float* partial, int n, int H, void* stream);
+/* graph sum-pool: pooled[b] = sum of rows graph_off[b]..graph_off[b+1]. src/modules/encoder.py:64-67 */
+int psvae_segment_pool_forward(const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
+                               int B, int width, void* stream);
+/* nn.GRU(batch_first, 1 layer) over T steps given gi = x W_ih^T + b_ih. src/modules/vae_piece_decoder.py:29,89 */
+int psvae_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
+                      float* hprev, float* gates, int B, int T, int R, void* stream);
+int psvae_gru_backward(const float* dhseq, const float* hprev, const float* gates, const float* whh,
+                       float* dgi, float* dgh, float* dh0, int B, int T, int R, void* stream);
+/* CrossEntropyLoss rows (ignore_index): row_loss, lse per row. src/modules/vae_piece_decoder.py:53-54 */
+int psvae_softmax_ce_forward(const float* logits, int ld, const int32_t* target, int target_stride,
+                             int target_offset, int rows_per_group, int rows, int classes, int ignore_index,
+                             float* row_loss, float* lse, void* stream);
+
+/* ---- host-side batching (bit-exact integer work, no GPU involved) ----------
+ * psvae_collate_pairs = the edge / pair enumeration loop of process_step3
+ * (src/data/bpe_dataset.py:110-132).  `ad` and `cross` are the molecules' dense
+ * bond-type and cross-piece matrices (n_i*n_i bytes each, concatenated).
+ * `mt_state` is CPython's `random.getstate()[1]` (624 words + index): the
+ * function consumes draws exactly where the reference calls random() and
+ * leaves the advanced state in place for `random.setstate`.
+ * Outputs use the reference's padded numbering (atom a of graph i = a + N*i). */
+int psvae_collate_pairs(int B, int N, const int32_t* n_atoms, const int8_t* ad, const int8_t* cross,
+                        double neg_rate, uint32_t* mt_state,
+                        int32_t* e_src, int32_t* e_dst, int32_t* e_type, int64_t e_cap, int64_t* n_edges,
+                        int32_t* in_piece_idx, int64_t* n_in_piece,
+                        int32_t* pair_graph, int32_t* pair_m, int32_t* pair_n, int32_t* pair_gold,
+                        int64_t pair_cap, int64_t* n_pairs);
+/* Build the packed index blob of psvae_batch from padded-numbering arrays.
+ * `blob` receives int32 words; `offsets[PSVAE_BLOB_FIELDS]` the start of each
+ * field inside it (field order = PSVAE_BLOB_* below).  Returns words used via
+ * *blob_words; PSVAE_E_CAPACITY when blob_cap is too small. */
+enum {
+    PSVAE_BLOB_ATOM_ID = 0, PSVAE_BLOB_PIECE_ID, PSVAE_BLOB_POS_ID, PSVAE_BLOB_NODE_GRAPH, PSVAE_BLOB_GRAPH_OFF,
+    PSVAE_BLOB_ROWPTR, PSVAE_BLOB_COL, PSVAE_BLOB_ETYPE, PSVAE_BLOB_ROWPTR_T, PSVAE_BLOB_COL_T, PSVAE_BLOB_ETYPE_T,
+    PSVAE_BLOB_IN_ROWPTR, PSVAE_BLOB_IN_COL, PSVAE_BLOB_IN_ETYPE, PSVAE_BLOB_IN_ROWPTR_T, PSVAE_BLOB_IN_COL_T,
+    PSVAE_BLOB_IN_ETYPE_T, PSVAE_BLOB_PAIR_SRC, PSVAE_BLOB_PAIR_DST, PSVAE_BLOB_PAIR_GRAPH, PSVAE_BLOB_PAIR_GOLD,
+    PSVAE_BLOB_PAIR_BY_SRC_PTR, PSVAE_BLOB_PAIR_BY_SRC_IDX, PSVAE_BLOB_PAIR_BY_DST_PTR, PSVAE_BLOB_PAIR_BY_DST_IDX,
+    PSVAE_BLOB_PAIR_GRAPH_OFF, PSVAE_BLOB_PIECES, PSVAE_BLOB_ATOM_ROWS_PTR, PSVAE_BLOB_ATOM_ROWS_IDX,
+    PSVAE_BLOB_PIECE_ROWS_PTR, PSVAE_BLOB_PIECE_ROWS_IDX, PSVAE_BLOB_POS_ROWS_PTR, PSVAE_BLOB_POS_ROWS_IDX,
+    PSVAE_BLOB_SEQ_ROWS_PTR, PSVAE_BLOB_SEQ_ROWS_IDX, PSVAE_BLOB_FIELDS
+};
+int64_t psvae_pack_bound(int B, int N, int64_t n_edges, int64_t n_pairs, int L, int num_atom, int num_piece, int max_pos);
+int psvae_pack_batch(int B, int N, int L, const int32_t* n_atoms,
+                     const int32_t* x, const int32_t* x_pieces, const int32_t* x_pos, /* [B,N] padded */
+                     const int32_t* e_src, const int32_t* e_dst, const int32_t* e_type, int64_t n_edges,
+                     const int32_t* in_piece_idx, int64_t n_in_piece,
+                     const int32_t* pair_graph, const int32_t* pair_m, const int32_t* pair_n,
+                     const int32_t* pair_gold, int64_t n_pairs,
+                     const int32_t* pieces, /* [B,L] */
+                     int num_atom, int num_piece, int max_pos, int pad_idx,
+                     int32_t* blob, int64_t blob_cap, int64_t* offsets, int64_t* blob_words,
+                     int32_t* n_nodes_out, int32_t* n_target_tokens_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSVAE_H */

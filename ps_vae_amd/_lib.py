@@ -1,0 +1,145 @@
+"""ctypes binding of libpsvae_hip.so (declarations mirror include/psvae.h).
+
+There is no fallback: if the shared library is missing or does not load, every
+entry point raises, so a silent CPU path can never stand in for the HIP one.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpsvae_hip.so')
+
+i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class Dims(C.Structure):
+    _fields_ = [(k, i32) for k in (
+        'num_piece', 'num_atom', 'num_bond', 'max_pos', 'd_atom', 'd_piece', 'd_pos', 'hidden', 'graph', 'latent',
+        'rnn', 'pred_hidden', 'n_props', 't_enc', 't_dec', 'pad_idx')] + [('eps_enc', f32), ('eps_dec', f32)]
+
+
+PARAM_FIELDS = (
+    'pred_w0', 'pred_b0', 'pred_w1', 'pred_b1', 'pred_wo', 'pred_bo',
+    'enc_node_w', 'enc_node_b', 'enc_edge_w', 'enc_edge_b', 'enc_w1', 'enc_b1', 'enc_w2', 'enc_b2',
+    'enc_lin_w', 'enc_lin_b', 'atom_emb', 'piece_emb', 'pos_emb', 'l2h_w', 'l2h_b',
+    'gru_wih', 'gru_whh', 'gru_bih', 'gru_bhh', 'vocab_w', 'vocab_b',
+    'dec_node_w', 'dec_node_b', 'dec_edge_w', 'dec_edge_b', 'dec_w1', 'dec_b1', 'dec_w2', 'dec_b2',
+    'sc_w0', 'sc_b0', 'sc_w1', 'sc_b1', 'sc_w2', 'sc_b2', 'sc_w3', 'sc_b3',
+    'mean_w', 'mean_b', 'lvar_w', 'lvar_b')
+
+# struct field -> state-dict key of the reference model
+PARAM_KEYS = {
+    'pred_w0': 'predictor.mlp.0.weight', 'pred_b0': 'predictor.mlp.0.bias',
+    'pred_w1': 'predictor.mlp.2.weight', 'pred_b1': 'predictor.mlp.2.bias',
+    'pred_wo': 'predictor.output.weight', 'pred_bo': 'predictor.output.bias',
+    'enc_node_w': 'encoder.node_trans.weight', 'enc_node_b': 'encoder.node_trans.bias',
+    'enc_edge_w': 'encoder.edge_trans.weight', 'enc_edge_b': 'encoder.edge_trans.bias',
+    'enc_w1': 'encoder.conv.nn.seq.0.weight', 'enc_b1': 'encoder.conv.nn.seq.0.bias',
+    'enc_w2': 'encoder.conv.nn.seq.2.weight', 'enc_b2': 'encoder.conv.nn.seq.2.bias',
+    'enc_lin_w': 'encoder.linear.weight', 'enc_lin_b': 'encoder.linear.bias',
+    'atom_emb': 'decoder.atom_embedding.weight', 'piece_emb': 'decoder.piece_embedding.weight',
+    'pos_emb': 'decoder.pos_embedding.weight',
+    'l2h_w': 'decoder.latent_to_rnn_hidden.weight', 'l2h_b': 'decoder.latent_to_rnn_hidden.bias',
+    'gru_wih': 'decoder.rnn.weight_ih_l0', 'gru_whh': 'decoder.rnn.weight_hh_l0',
+    'gru_bih': 'decoder.rnn.bias_ih_l0', 'gru_bhh': 'decoder.rnn.bias_hh_l0',
+    'vocab_w': 'decoder.to_vocab.weight', 'vocab_b': 'decoder.to_vocab.bias',
+    'dec_node_w': 'decoder.graph_embedding.node_trans.weight', 'dec_node_b': 'decoder.graph_embedding.node_trans.bias',
+    'dec_edge_w': 'decoder.graph_embedding.edge_trans.weight', 'dec_edge_b': 'decoder.graph_embedding.edge_trans.bias',
+    'dec_w1': 'decoder.graph_embedding.conv.nn.seq.0.weight', 'dec_b1': 'decoder.graph_embedding.conv.nn.seq.0.bias',
+    'dec_w2': 'decoder.graph_embedding.conv.nn.seq.2.weight', 'dec_b2': 'decoder.graph_embedding.conv.nn.seq.2.bias',
+    'sc_w0': 'decoder.edge_predictor.0.seq.0.weight', 'sc_b0': 'decoder.edge_predictor.0.seq.0.bias',
+    'sc_w1': 'decoder.edge_predictor.0.seq.2.weight', 'sc_b1': 'decoder.edge_predictor.0.seq.2.bias',
+    'sc_w2': 'decoder.edge_predictor.0.seq.4.weight', 'sc_b2': 'decoder.edge_predictor.0.seq.4.bias',
+    'sc_w3': 'decoder.edge_predictor.1.weight', 'sc_b3': 'decoder.edge_predictor.1.bias',
+    'mean_w': 'decoder.W_mean.weight', 'mean_b': 'decoder.W_mean.bias',
+    'lvar_w': 'decoder.W_log_var.weight', 'lvar_b': 'decoder.W_log_var.bias',
+}
+
+
+class Params(C.Structure):
+    _fields_ = [(k, vp) for k in PARAM_FIELDS]
+
+
+BATCH_PTRS = (
+    'atom_id', 'piece_id', 'pos_id', 'node_graph', 'graph_off',
+    'rowptr', 'col', 'etype', 'rowptr_t', 'col_t', 'etype_t',
+    'in_rowptr', 'in_col', 'in_etype', 'in_rowptr_t', 'in_col_t', 'in_etype_t',
+    'pair_src', 'pair_dst', 'pair_graph', 'pair_gold',
+    'pair_by_src_ptr', 'pair_by_src_idx', 'pair_by_dst_ptr', 'pair_by_dst_idx', 'pair_graph_off', 'pieces',
+    'atom_rows_ptr', 'atom_rows_idx', 'piece_rows_ptr', 'piece_rows_idx', 'pos_rows_ptr', 'pos_rows_idx',
+    'seq_rows_ptr', 'seq_rows_idx')
+# index-blob field order (enum PSVAE_BLOB_* of the header) - identical to BATCH_PTRS
+BLOB_FIELDS = BATCH_PTRS
+
+
+class Batch(C.Structure):
+    _fields_ = ([(k, i32) for k in ('B', 'n', 'E', 'E_in', 'S', 'L')] + [(k, vp) for k in BATCH_PTRS] +
+                [('props', vp), ('eps', vp), ('denoms', vp)])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m ps_vae_amd.build` '
+                           '(there is no CPU fallback for the HIP kernels)')
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.psvae_strerror.restype = C.c_char_p
+    L.psvae_strerror.argtypes = [C.c_int]
+    L.psvae_abi_version.restype = C.c_int
+    L.psvae_workspace_bytes.restype = sz
+    L.psvae_workspace_bytes.argtypes = [P(Dims), P(Batch)]
+    L.psvae_workspace_offset.restype = i64
+    L.psvae_workspace_offset.argtypes = [P(Dims), P(Batch), C.c_char_p]
+    L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp]
+    L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, P(Params), vp]
+    L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
+    L.psvae_adam_partials.restype = sz
+    L.psvae_adam_partials.argtypes = [i64]
+    L.psvae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]
+    L.psvae_linear_scratch_bytes.restype = sz
+    L.psvae_linear_scratch_bytes.argtypes = [C.c_int] * 4
+    L.psvae_linear_forward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, vp]
+    L.psvae_linear_backward_input.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
+    L.psvae_linear_backward_weight.argtypes = [vp, C.c_int, i64, vp, C.c_int, i64, C.c_int, vp, vp, C.c_int, C.c_int,
+                                               C.c_int, vp, sz, vp]
+    L.psvae_gine_aggregate_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_gine_aggregate_backward.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, vp, vp,
+                                                C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_gine_edge_grad_scratch.restype = sz
+    L.psvae_gine_edge_grad_scratch.argtypes = [C.c_int, C.c_int]
+    L.psvae_gine_edge_grad.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    L.psvae_segment_pool_forward.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_gru_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_gru_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_softmax_ce_forward.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.psvae_collate_pairs.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp, i64, P(i64), vp, P(i64),
+                                      vp, vp, vp, vp, i64, P(i64)]
+    L.psvae_pack_bound.restype = i64
+    L.psvae_pack_bound.argtypes = [C.c_int, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.psvae_pack_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp,
+                                   i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, P(i64), P(i32), P(i32)]
+    if L.psvae_abi_version() != 1:
+        raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
+    _lib = L
+    return L
+
+
+EXPORTS = (
+    'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward',
+    'psvae_step_backward', 'psvae_encode', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
+    'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
+    'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
+    'psvae_gine_edge_grad', 'psvae_segment_pool_forward',
+    'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
+    'psvae_pack_bound', 'psvae_pack_batch')
+
+
+def check(rc, what='psvae call'):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed: {lib().psvae_strerror(rc).decode()} (code {rc})')

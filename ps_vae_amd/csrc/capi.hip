@@ -1,0 +1,115 @@
+// extern "C" surface for the single operators (thin argument checks around the
+// same launchers the whole-step entry points use).
+#include "psvae_internal.h"
+
+extern "C" const char* psvae_strerror(int code) {
+    switch (code) {
+        case PSVAE_OK: return "ok";
+        case PSVAE_E_NULL: return "psvae: a required pointer is NULL";
+        case PSVAE_E_SHAPE: return "psvae: a size argument is negative, inconsistent or unsupported";
+        case PSVAE_E_ALIGN: return "psvae: pointer or leading dimension violates an alignment rule (16 bytes / multiple of 4)";
+        case PSVAE_E_WORKSPACE: return "psvae: workspace or scratch buffer too small";
+        case PSVAE_E_CAPACITY: return "psvae: host output buffer too small";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "psvae: unknown error code";
+}
+
+extern "C" int psvae_abi_version(void) { return PSVAE_ABI_VERSION; }
+
+extern "C" int psvae_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                               float* partials, float max_norm, float lr, float beta1, float beta2, float adam_eps,
+                               float bias1, float bias2, float* grad_norm_out, void* stream) {
+    return clip_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, count, partials, max_norm, lr, beta1, beta2,
+                     adam_eps, bias1, bias2, grad_norm_out);
+}
+
+extern "C" size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg) {
+    size_t a = gemm_scratch_floats(M, N, K, 1, false);          // forward
+    size_t b = gemm_scratch_floats(N, K + 1, M, nseg, true);     // weight gradient
+    return (a > b ? a : b) * sizeof(float) + 256;
+}
+
+extern "C" int psvae_linear_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                                    int M, int N, int K, int relu, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!x || !w || !y) return PSVAE_E_NULL;
+    if (M < 0 || N < 1 || K < 1 || ldx < K || ldy < N) return PSVAE_E_SHAPE;
+    return linear_fwd((hipStream_t)stream, x, ldx, w, b, y, ldy, M, N, K, relu, (float*)scratch, scratch_bytes / sizeof(float));
+}
+
+extern "C" int psvae_linear_backward_input(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                           int M, int N, int K, const float* mask, int ldmask, int accumulate, void* stream) {
+    if (!dy || !w || !dx) return PSVAE_E_NULL;
+    if (M < 0 || N < 1 || K < 1 || lddy < N || lddx < K || (mask && ldmask < K)) return PSVAE_E_SHAPE;
+    return linear_bwd_x((hipStream_t)stream, dy, lddy, w, dx, lddx, M, N, K, mask, ldmask, accumulate);
+}
+
+extern "C" int psvae_linear_backward_weight(const float* dy, int lddy, int64_t seg_stride_dy, const float* x, int ldx,
+                                            int64_t seg_stride_x, int nseg, float* dw, float* db, int M, int N, int K,
+                                            void* scratch, size_t scratch_bytes, void* stream) {
+    if (!dy || !x || !dw) return PSVAE_E_NULL;
+    if (M < 0 || N < 1 || K < 1 || nseg < 1 || lddy < N || ldx < K) return PSVAE_E_SHAPE;
+    return linear_bwd_w((hipStream_t)stream, dy, lddy, seg_stride_dy, x, ldx, seg_stride_x, nseg, dw, db, M, N, K,
+                        (float*)scratch, scratch_bytes / sizeof(float));
+}
+
+extern "C" int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
+                                            const int32_t* etype, const float* edge_w, const float* edge_b,
+                                            float one_plus_eps, float* out, int ldo, int n, int H, void* stream) {
+    if (!x || !rowptr || !edge_w || !edge_b || !out) return PSVAE_E_NULL;
+    if (n < 0 || H < 4 || ldx < H || ldo < H) return PSVAE_E_SHAPE;
+    AggGroup g{x, out, rowptr, col, etype, edge_w, edge_b, one_plus_eps};
+    return gine_agg_fwd((hipStream_t)stream, &g, 1, ldx, ldo, n, H);
+}
+
+extern "C" int psvae_gine_aggregate_backward(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr_t,
+                                             const int32_t* col_t, const int32_t* etype_t, const float* edge_w,
+                                             const float* edge_b, float one_plus_eps, const float* dpool, int ldp,
+                                             const int32_t* node_graph, float* dx, int lddx, int n, int H, void* stream) {
+    if (!dx || (da && (!x || !rowptr_t || !edge_w || !edge_b))) return PSVAE_E_NULL;
+    if (n < 0 || H < 4 || lddx < H) return PSVAE_E_SHAPE;
+    AggBwdGroup g{da, x, dx, rowptr_t, col_t, etype_t, edge_w, edge_b, one_plus_eps, dpool};
+    return gine_agg_bwd((hipStream_t)stream, &g, 1, da ? ldda : H, da ? ldx : H, lddx, dpool ? ldp : H, node_graph, n, H);
+}
+
+extern "C" size_t psvae_gine_edge_grad_scratch(int n, int H) { return (size_t)etab_chunks(n) * 4 * H; }
+
+extern "C" int psvae_gine_edge_grad(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr,
+                                    const int32_t* col, const int32_t* etype, const float* edge_w, const float* edge_b,
+                                    float* d_edge_w, float* d_edge_b, float* partial, int n, int H, void* stream) {
+    if (!da || !x || !rowptr || !edge_w || !edge_b || !d_edge_w || !d_edge_b || !partial) return PSVAE_E_NULL;
+    if (n < 0 || H < 4 || ldda < H || ldx < H) return PSVAE_E_SHAPE;
+    EtabGroup g{da, 0, x, 0, rowptr, col, etype, edge_w, edge_b, d_edge_w, d_edge_b, partial};
+    return gine_etab_grad((hipStream_t)stream, &g, 1, 1, ldda, ldx, n, H, etab_chunks(n));
+}
+
+extern "C" int psvae_segment_pool_forward(const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
+                                          int B, int width, void* stream) {
+    if (!x || !graph_off || !pooled) return PSVAE_E_NULL;
+    if (B < 0 || width < 4 || ldx < width || ldp < width) return PSVAE_E_SHAPE;
+    return segment_pool_fwd((hipStream_t)stream, x, ldx, graph_off, pooled, ldp, B, width);
+}
+
+extern "C" int psvae_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
+                                 float* hprev, float* gates, int B, int T, int R, void* stream) {
+    if (!gi || !h0 || !whh || !bhh || !hseq || !hprev || !gates) return PSVAE_E_NULL;
+    if (B < 0 || T < 0 || R < 4) return PSVAE_E_SHAPE;
+    return gru_fwd((hipStream_t)stream, gi, h0, whh, bhh, hseq, hprev, gates, B, T, R);
+}
+
+extern "C" int psvae_gru_backward(const float* dhseq, const float* hprev, const float* gates, const float* whh,
+                                  float* dgi, float* dgh, float* dh0, int B, int T, int R, void* stream) {
+    if (!dhseq || !hprev || !gates || !whh || !dgi || !dgh || !dh0) return PSVAE_E_NULL;
+    if (B < 0 || T < 0 || R < 4) return PSVAE_E_SHAPE;
+    return gru_bwd((hipStream_t)stream, dhseq, hprev, gates, whh, dgi, dgh, dh0, B, T, R);
+}
+
+extern "C" int psvae_softmax_ce_forward(const float* logits, int ld, const int32_t* target, int target_stride,
+                                        int target_offset, int rows_per_group, int rows, int classes, int ignore_index,
+                                        float* row_loss, float* lse, void* stream) {
+    if (!logits || !target || !row_loss || !lse) return PSVAE_E_NULL;
+    if (rows < 0 || classes < 1 || ld < classes) return PSVAE_E_SHAPE;
+    return softmax_ce_fwd((hipStream_t)stream, logits, ld, target, target_stride, target_offset, rows_per_group, rows, classes,
+                          ignore_index, row_loss, lse);
+}

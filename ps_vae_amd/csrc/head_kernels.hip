@@ -1,0 +1,258 @@
+// Small kernels around the latent: reparameterisation + KL, cross-entropy rows,
+// MSE, loss finalisation, and the fused global-norm clip + Adam update.
+// Loss denominators and upstream loss gradients are read from DEVICE memory
+// (`denoms`, `gscale`) so that no launch depends on a host round trip.
+#include "psvae_internal.h"
+
+namespace {
+
+// rsample (src/modules/vae_piece_decoder.py:56-63): thread per graph.
+__global__ void vae_head_fwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, float* __restrict__ z,
+                                    float* __restrict__ klrow, int B, int Z) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* mu = mulv + (long long)b * 2 * Z;
+    const float* raw = mu + Z;
+    float s = 0.f;
+    for (int k = 0; k < Z; ++k) {
+        const float m = mu[k], lv = -fabsf(raw[k]);
+        s += 1.0f + lv - m * m - expf(lv);
+        z[(long long)b * Z + k] = m + expf(lv * 0.5f) * eps[(long long)b * Z + k];
+    }
+    klrow[b] = s;
+}
+
+// d(mean | raw log-var) from dz and the KL term; gscale[3] = dL/dkl, denoms[2] = B.
+__global__ void vae_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
+                                    const float* __restrict__ gscale, const float* __restrict__ denoms,
+                                    float* __restrict__ dmulv, int B, int Z) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * Z) return;
+    const int b = t / Z, k = t - b * Z;
+    const float gk = gscale[3] / denoms[2];
+    const float m = mulv[(long long)b * 2 * Z + k], raw = mulv[(long long)b * 2 * Z + Z + k];
+    const float lv = -fabsf(raw), d = dz[t];
+    const float dmu = d + gk * m;
+    const float dlv = d * eps[t] * 0.5f * expf(lv * 0.5f) + gk * (-0.5f) * (1.0f - expf(lv));
+    const float sgn = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
+    dmulv[(long long)b * 2 * Z + k] = dmu;
+    dmulv[(long long)b * 2 * Z + Z + k] = -sgn * dlv;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int ce_target(const int32_t* target, int tstride, int toffset, int rpg, int r) {
+    return target[(long long)(r / rpg) * tstride + toffset + (r % rpg)];
+}
+
+// One wave per row: lse and the row's loss (0 for ignored rows).
+__global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __restrict__ logits, int ld,
+                                                             const int32_t* __restrict__ target, int tstride, int toffset,
+                                                             int rpg, int rows, int classes, int ignore_index,
+                                                             float* __restrict__ row_loss, float* __restrict__ lse_out) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* x = logits + (long long)r * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < classes; c += 64) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < classes; c += 64) s += expf(x[c] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    if (lane == 0) {
+        const int tg = ce_target(target, tstride, toffset, rpg, r);
+        lse_out[r] = lse;
+        row_loss[r] = (tg == ignore_index) ? 0.f : lse - x[tg];
+    }
+}
+
+// In place: logits <- (softmax - onehot) * gscale[gidx] / denoms[didx]  (0 for ignored rows)
+__global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(float* __restrict__ logits, int ld,
+                                                             const int32_t* __restrict__ target, int tstride, int toffset,
+                                                             int rpg, int rows, int classes, int ignore_index,
+                                                             const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                             int gidx, const float* __restrict__ denoms, int didx) {
+    const long long total = (long long)rows * classes;
+    const float scale = gscale[gidx] / denoms[didx];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(t / classes), c = (int)(t - (long long)r * classes);
+        const int tg = ce_target(target, tstride, toffset, rpg, r);
+        float* p = logits + (long long)r * ld + c;
+        *p = (tg == ignore_index) ? 0.f : (expf(*p - lse[r]) - (c == tg ? 1.f : 0.f)) * scale;
+    }
+}
+
+__global__ void mse_fwd_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ gold,
+                               float* __restrict__ row, int B, int P) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int k = 0; k < P; ++k) {
+        const float d = pred[(long long)b * ldp + k] - gold[(long long)b * P + k];
+        s += d * d;
+    }
+    row[b] = s;
+}
+__global__ void mse_bwd_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ gold,
+                               const float* __restrict__ gscale, const float* __restrict__ denoms,
+                               float* __restrict__ dpred, int B, int P) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * P) return;
+    const int b = t / P, k = t - b * P;
+    dpred[(long long)b * ldp + k] = 2.0f * (pred[(long long)b * ldp + k] - gold[t]) * gscale[0] / denoms[3];
+}
+
+// Block-wide sum in a fixed order: thread-strided partials, then an LDS tree.
+__device__ float block_sum_256(const float* __restrict__ v, int n, float* sh) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+// losses = [pred, rec, piece, edge, kl]
+__global__ __launch_bounds__(256) void losses_finalize_kernel(const float* mse_row, int B, const float* piece_row, int rows_p,
+                                                              const float* edge_row, int S, const float* klrow,
+                                                              const float* denoms, float* losses) {
+    __shared__ float sh[256];
+    const float mse = block_sum_256(mse_row, B, sh);
+    const float piece = block_sum_256(piece_row, rows_p, sh);
+    const float edge = block_sum_256(edge_row, S, sh);
+    const float kl = block_sum_256(klrow, B, sh);
+    if (threadIdx.x == 0) {
+        const float pl = piece / denoms[0], el = edge / denoms[1];
+        losses[0] = mse / denoms[3];
+        losses[1] = pl + el;
+        losses[2] = pl;
+        losses[3] = el;
+        losses[4] = -0.5f * kl / denoms[2];
+    }
+}
+
+// ---- clip_grad_norm_ + Adam ------------------------------------------------
+constexpr int NORM_BLOCKS = 512;
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long count, float* __restrict__ partials) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+// Every block re-derives the clip coefficient from the same partials in the same
+// order, so all blocks agree bit for bit.  torch: coef = min(1, max_norm / (norm + 1e-6)).
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long long count, const float* __restrict__ partials,
+                                                        float max_norm, float lr, float b1, float b2, float eps,
+                                                        float bias1, float bias2, float* __restrict__ norm_out) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < NORM_BLOCKS; i += 256) s += partials[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float norm = sqrtf(sh[0]);
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    const float step = lr / bias1, sqrt_b2 = sqrtf(bias2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi; g[i] = gi;
+        p[i] -= step * (mi / (sqrtf(vi) / sqrt_b2 + eps));
+    }
+}
+
+}  // namespace
+
+int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mulv, eps, z, klrow, B, Z);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz, const float* gscale,
+                 const float* denoms, float* dmulv, int B, int Z) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, s, mulv, eps, dz, gscale, denoms, dmulv, B, Z);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* target, int tstride, int toffset,
+                   int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse) {
+    if (rows == 0) return 0;
+    if (rows_per_group < 1) return PSVAE_E_SHAPE;
+    hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, ld, target, tstride, toffset,
+                       rows_per_group, rows, classes, ignore_index, row_loss, lse);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
+                   int rows_per_group, int rows, int classes, int ignore_index, const float* lse,
+                   const float* gscale, int gidx, const float* denoms, int didx) {
+    if (rows == 0) return 0;
+    long long total = (long long)rows * classes;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3(blocks), dim3(256), 0, s, logits_inout, ld, target, tstride, toffset,
+                       rows_per_group, rows, classes, ignore_index, lse, gscale, gidx, denoms, didx);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float* row, int B, int P) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, pred, ldp, gold, row, B, P);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const float* gscale, const float* denoms,
+            float* dpred, int B, int P) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((B * P + 255) / 256), dim3(256), 0, s, pred, ldp, gold, gscale, denoms, dpred, B, P);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* piece_row, int rows_p,
+                    const float* edge_row, int S, const float* klrow, const float* denoms, float* losses) {
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(256), 0, s, mse_row, B, piece_row, rows_p, edge_row, S, klrow, denoms, losses);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t psvae_adam_partials(int64_t) { return NORM_BLOCKS; }
+
+int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count, float* partials,
+              float max_norm, float lr, float b1, float b2, float eps, float bias1, float bias2, float* norm_out) {
+    if (count <= 0) return 0;
+    if (!p || !g || !m || !v || !partials) return PSVAE_E_NULL;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, g, (long long)count, partials);
+    PSVAE_LAUNCH_CHECK();
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, (long long)count, partials, max_norm, lr,
+                       b1, b2, eps, bias1, bias2, norm_out);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,125 @@
+// Internal declarations shared by the HIP translation units of libpsvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/psvae.h"
+
+#define PSVAE_LAUNCH_CHECK()                                   \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return (int)e__;                \
+    } while (0)
+#define PSVAE_TRY(expr)                                        \
+    do {                                                       \
+        int rc__ = (expr);                                     \
+        if (rc__ != 0) return rc__;                            \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- GEMM family
+// C[i][j] (+)= epilogue( sum_r A(i,r) * B(j,r) ), fp32 in / fp32 accumulate on
+// v_mfma_f32_32x32x2_f32.  A(i,r) = A[i*lda + r] or, when a_t, A[r*lda + i]
+// (same for B).  grid.z enumerates nseg segments x splits reduction slices.
+struct GemmDesc {
+    const float* A = nullptr; const float* B = nullptr; float* C = nullptr;
+    int M = 0, N = 0, R = 0;
+    int lda = 0, ldb = 0, ldc = 0;
+    bool a_t = false, b_t = false;
+    const float* bias = nullptr;   // per column j
+    int relu = 0;
+    const float* mask = nullptr; int ldmask = 0;  // C = mask > 0 ? C : 0
+    int accumulate = 0;            // C += result
+    int ones_col = -1;             // column j of B that reads as 1.0 (bias-gradient trick); counts inside N
+    float* c_extra = nullptr;      // destination of column ones_col (length M)
+    // segments (grouped or summed)
+    int nseg = 1;
+    int64_t seg_a = 0, seg_b = 0, seg_c = 0, seg_bias = 0, seg_mask = 0;
+    bool sum_segments = false;     // true: all segments add into one C (weight gradients)
+    // scratch for split reductions
+    float* scratch = nullptr; size_t scratch_floats = 0;
+};
+int gemm_f32(hipStream_t s, const GemmDesc& d);
+size_t gemm_scratch_floats(int M, int N, int R, int nseg, bool sum_segments);
+
+// Linear-layer helpers on top of gemm_f32
+int linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+               int M, int N, int K, int relu, float* scratch, size_t scratch_floats);
+int linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w, float* dx, int lddx,
+                 int M, int N, int K, const float* mask, int ldmask, int accumulate);
+int linear_bwd_w(hipStream_t s, const float* dy, int lddy, int64_t seg_dy, const float* x, int ldx, int64_t seg_x,
+                 int nseg, float* dw, float* db, int M, int N, int K, float* scratch, size_t scratch_floats);
+
+// ------------------------------------------------------------ graph kernels
+struct AggGroup {  // one GINE stack (encoder or decoder-side encoder)
+    const float* x; float* out;           // layer input / aggregated output
+    const int32_t *rowptr, *col, *etype;
+    const float *edge_w, *edge_b;
+    float ope;                            // 1 + eps
+};
+int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo, int n, int H);
+struct AggBwdGroup {
+    const float* da;        // may be null: only the pooled-gradient broadcast is written
+    const float* x;         // the layer's input (for the ReLU mask)
+    float* dx;
+    const int32_t *rowptr_t, *col_t, *etype_t;
+    const float *edge_w, *edge_b;
+    float ope;
+    const float* dpool;     // [B, ldp] slice start, or null
+};
+int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int ldx, int lddx, int ldp,
+                 const int32_t* node_graph, int n, int H);
+struct EtabGroup {
+    const float* da; int64_t da_layer;    // [t][n][H]
+    const float* x; int64_t x_layer;      // layer l input = x + l*x_layer, row stride ldx
+    const int32_t *rowptr, *col, *etype;
+    const float *edge_w, *edge_b;
+    float* d_edge_w; float* d_edge_b;     // outputs [H,4], [H]
+    float* partial;                       // scratch [t*chunks][4][H]
+};
+int gine_etab_grad(hipStream_t s, const EtabGroup* g, int ngroups, int t, int ldda, int ldx, int n, int H, int chunks);
+static inline int etab_chunks(int n) { int c = (n + 127) / 128; return c < 1 ? 1 : (c > 64 ? 64 : c); }
+
+int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32_t* q, const float* ta,
+                  const float* tp, const float* tq, int da, int dp, int dq, float* out, int n);
+int rows_gather(hipStream_t s, const int32_t* idx, int idx_stride_outer, int inner, int idx_ld, const float* table,
+                int width, float* out, int rows);
+// dTable[row] = sum over list1 of src1[idx, off1 .. off1+D) + sum over list2 of src2[idx, off2 ..)
+int table_grad(hipStream_t s, float* dtable, int rows, int D, const int32_t* ptr1, const int32_t* idx1,
+               const float* src1, int ld1, int off1, const int32_t* ptr2, const int32_t* idx2, const float* src2,
+               int ld2, int off2);
+int segment_pool_fwd(hipStream_t s, const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
+                     int B, int width);
+int pair_gather(hipStream_t s, const float* emb, int lde, const float* z, const int32_t* src, const int32_t* dst,
+                const int32_t* graph, float* out, int S, int H, int Z);
+int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_ptr, const int32_t* by_src_idx,
+                 const int32_t* by_dst_ptr, const int32_t* by_dst_idx, const int32_t* pair_graph_off, float* demb,
+                 int ldde, float* dz, int dz_accumulate, int n, int B, int H, int Z);
+
+// ------------------------------------------------------------ heads / losses
+int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z);
+int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz, const float* gscale,
+                 const float* denoms, float* dmulv, int B, int Z);
+int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* target, int tstride, int toffset,
+                   int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse);
+int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
+                   int rows_per_group, int rows, int classes, int ignore_index, const float* lse,
+                   const float* gscale, int gidx, const float* denoms, int didx);
+int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float* row, int B, int P);
+int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const float* gscale, const float* denoms,
+            float* dpred, int B, int P);
+int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* piece_row, int rows_p,
+                    const float* edge_row, int S, const float* klrow, const float* denoms, float* losses);
+int fill_zero(hipStream_t s, float* p, int64_t count);
+
+// ------------------------------------------------------------ GRU
+int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
+            float* hprev, float* gates, int B, int T, int R);
+int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
+            float* dgi, float* dgh, float* dh0, int B, int T, int R);
+
+// ------------------------------------------------------------ optimiser
+int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count, float* partials,
+              float max_norm, float lr, float b1, float b2, float eps, float bias1, float bias2, float* norm_out);

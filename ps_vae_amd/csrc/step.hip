@@ -1,0 +1,409 @@
+// Host-side sequencing of the whole training step: one call enqueues every
+// kernel of PSVAEModel.forward (or its backward) on the caller's stream.
+//
+// Packed layout: all node tensors have n rows (real atoms only).  Each GINE
+// stack keeps its node_trans output and its t layer outputs side by side in one
+// [n, (t+1)*H] matrix ("layer stack"): slice l is the input of layer l, slices
+// 1..t are the reference's all_x, slice t its last-layer embedding.  When both
+// stacks run the same number of iterations, every per-layer launch handles the
+// encoder and the decoder-side encoder together (grid dimension = group).
+#include "psvae_internal.h"
+#include <string.h>
+
+namespace {
+
+struct Sz {
+    int B, n, S, L, T, BT;
+    int Da, Dp, Dq, Din, H, G, Z, R, V2, P, P2, Hp, NP, te, td;
+    int ldl, ldpred;
+};
+
+Sz sizes(const psvae_dims& d, const psvae_batch& b) {
+    Sz s;
+    s.B = b.B; s.n = b.n; s.S = b.S; s.L = b.L; s.T = b.L > 0 ? b.L - 1 : 0; s.BT = s.B * s.T;
+    s.Da = d.d_atom; s.Dp = d.d_piece; s.Dq = d.d_pos; s.Din = s.Da + s.Dp + s.Dq;
+    s.H = d.hidden; s.G = d.graph; s.Z = d.latent; s.R = d.rnn;
+    s.V2 = d.num_piece; s.P = 2 * d.hidden + d.latent; s.P2 = s.P / 2; s.Hp = d.pred_hidden; s.NP = d.n_props;
+    s.te = d.t_enc; s.td = d.t_dec;
+    s.ldl = (int)round_up(s.V2, 4); s.ldpred = (int)round_up(s.NP, 4);
+    return s;
+}
+
+int check_dims(const psvae_dims* d, const psvae_batch* b) {
+    if (!d || !b) return PSVAE_E_NULL;
+    if (d->num_bond != 4) return PSVAE_E_SHAPE;
+    if (d->hidden <= 0 || d->hidden % 4 || d->latent <= 0 || d->latent % 4 || d->rnn <= 0 || d->rnn % 4) return PSVAE_E_ALIGN;
+    if (d->t_enc < 1 || d->t_dec < 1 || d->graph < 1 || d->pred_hidden < 1 || d->n_props < 1) return PSVAE_E_SHAPE;
+    if (d->d_atom < 1 || d->d_piece < 1 || d->d_pos < 1 || d->num_piece < 3) return PSVAE_E_SHAPE;
+    if (b->B < 1 || b->n < 1 || b->E < 0 || b->E_in < 0 || b->S < 0 || b->L < 2) return PSVAE_E_SHAPE;
+    return 0;
+}
+
+struct WS {
+    // forward (saved for backward)
+    float *X0, *XE, *XD, *AE, *AD, *HE, *HD, *pooled, *cond, *mulv, *z, *klrow;
+    float *semb, *gi, *h0, *hseq, *hprev, *gates, *logits, *rowloss_p, *lse_p;
+    float *pin, *s1, *s2, *s3, *slog, *rowloss_e, *lse_e, *q1, *q2, *pred, *mse_row, *losses;
+    // backward
+    float *dpred, *dq2, *dq1, *dz, *dhseq, *dgi, *dgh, *dh0, *dsemb, *ds3, *ds2, *ds1, *dpin;
+    float *dmulv, *dcond, *dpooled, *GE, *GD, *G0, *DHE, *DHD, *DAE, *DAD, *dX0, *etab_part;
+    float *scratch; size_t scratch_floats;
+    size_t total_floats;
+};
+
+struct Field { const char* name; float* WS::*member; size_t count; };
+
+// One table drives both the size query and the pointer carve-up.
+size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_off) {
+    const size_t n = s.n, B = s.B, S = s.S, BT = s.BT, H = s.H;
+    const size_t tmax = s.te > s.td ? s.te : s.td;
+    size_t maxw = (size_t)s.H * (s.H + 1);
+    auto upw = [&](size_t rows, size_t cols) { if (rows * (cols + 1) > maxw) maxw = rows * (cols + 1); };
+    upw(s.H, s.Din); upw(2 * s.H, s.Din); upw(s.G, s.te * s.H); upw(s.V2, s.R); upw(3 * s.R, s.R); upw(3 * s.R, s.Dp);
+    upw(s.P2, s.P); upw(s.P, s.P2); upw(s.P2, s.P2); upw(2 * s.Z, s.G); upw(s.Hp, s.Hp); upw(s.Hp, s.Z); upw(s.R, s.Z);
+    const size_t scratch = ((size_t)1 << 21) + tmax * maxw;
+    const size_t chunks = etab_chunks(s.n);
+    const Field f[] = {
+        {"x0", &WS::X0, n * s.Din},
+        {"enc_stack", &WS::XE, n * (s.te + 1) * H}, {"dec_stack", &WS::XD, n * (s.td + 1) * H},
+        {"enc_agg", &WS::AE, n * s.te * H}, {"dec_agg", &WS::AD, n * s.td * H},
+        {"enc_hid", &WS::HE, n * s.te * H}, {"dec_hid", &WS::HD, n * s.td * H},
+        {"pooled", &WS::pooled, B * s.te * H}, {"cond", &WS::cond, B * s.G}, {"mulv", &WS::mulv, B * 2 * s.Z},
+        {"z", &WS::z, B * s.Z}, {"klrow", &WS::klrow, B},
+        {"seq_emb", &WS::semb, BT * s.Dp}, {"gi", &WS::gi, BT * 3 * s.R}, {"h0", &WS::h0, B * s.R},
+        {"rnn_out", &WS::hseq, BT * s.R}, {"rnn_prev", &WS::hprev, BT * s.R}, {"gates", &WS::gates, BT * 4 * s.R},
+        {"logits", &WS::logits, BT * s.ldl}, {"piece_rowloss", &WS::rowloss_p, BT}, {"piece_lse", &WS::lse_p, BT},
+        {"pair_in", &WS::pin, S * s.P}, {"pair_h1", &WS::s1, S * s.P2}, {"pair_h2", &WS::s2, S * s.P2},
+        {"pair_h3", &WS::s3, S * s.P}, {"pair_logits", &WS::slog, S * 4}, {"edge_rowloss", &WS::rowloss_e, S},
+        {"edge_lse", &WS::lse_e, S}, {"pred_h1", &WS::q1, B * s.Hp}, {"pred_h2", &WS::q2, B * s.Hp},
+        {"pred", &WS::pred, B * s.ldpred}, {"mse_row", &WS::mse_row, B}, {"losses", &WS::losses, 8},
+        {"d_pred", &WS::dpred, B * s.ldpred}, {"d_pred_h2", &WS::dq2, B * s.Hp}, {"d_pred_h1", &WS::dq1, B * s.Hp},
+        {"d_z", &WS::dz, B * s.Z}, {"d_rnn_out", &WS::dhseq, BT * s.R}, {"d_gi", &WS::dgi, BT * 3 * s.R},
+        {"d_gh", &WS::dgh, BT * 3 * s.R}, {"d_h0", &WS::dh0, B * s.R}, {"d_seq_emb", &WS::dsemb, BT * s.Dp},
+        {"d_pair_h3", &WS::ds3, S * s.P}, {"d_pair_h2", &WS::ds2, S * s.P2}, {"d_pair_h1", &WS::ds1, S * s.P2},
+        {"d_pair_in", &WS::dpin, S * s.P}, {"d_mulv", &WS::dmulv, B * 2 * s.Z}, {"d_cond", &WS::dcond, B * s.G},
+        {"d_pooled", &WS::dpooled, B * s.te * H},
+        {"enc_g", &WS::GE, n * (s.te + 1) * H}, {"dec_g", &WS::GD, n * (s.td + 1) * H}, {"g0", &WS::G0, n * 2 * H},
+        {"enc_dhid", &WS::DHE, n * s.te * H}, {"dec_dhid", &WS::DHD, n * s.td * H},
+        {"enc_dagg", &WS::DAE, n * s.te * H}, {"dec_dagg", &WS::DAD, n * s.td * H},
+        {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * tmax * chunks * 4 * H},
+        {"scratch", &WS::scratch, scratch},
+    };
+    size_t off = 0;
+    for (const Field& e : f) {
+        if (w) w->*(e.member) = base + off;
+        if (want && want_off && strcmp(want, e.name) == 0) *want_off = (int64_t)off;
+        off += (size_t)round_up((int64_t)(e.count ? e.count : 1), 64);
+    }
+    if (w) { w->scratch_floats = scratch; w->total_floats = off; }
+    return off;
+}
+
+struct Stack {  // one GINE stack
+    float *X, *A, *Hid, *Gr, *DH, *DA;
+    const int32_t *rowptr, *col, *etype, *rowptr_t, *col_t, *etype_t;
+    const float *node_w, *node_b, *edge_w, *edge_b, *w1, *b1, *w2, *b2;
+    float *g_node_w, *g_node_b, *g_edge_w, *g_edge_b, *g_w1, *g_b1, *g_w2, *g_b2;
+    float ope; int t;
+};
+
+Stack enc_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* g, const psvae_batch& b, const WS& w) {
+    Stack k{};
+    k.X = w.XE; k.A = w.AE; k.Hid = w.HE; k.Gr = w.GE; k.DH = w.DHE; k.DA = w.DAE;
+    k.rowptr = b.rowptr; k.col = b.col; k.etype = b.etype; k.rowptr_t = b.rowptr_t; k.col_t = b.col_t; k.etype_t = b.etype_t;
+    k.node_w = p.enc_node_w; k.node_b = p.enc_node_b; k.edge_w = p.enc_edge_w; k.edge_b = p.enc_edge_b;
+    k.w1 = p.enc_w1; k.b1 = p.enc_b1; k.w2 = p.enc_w2; k.b2 = p.enc_b2;
+    if (g) { k.g_node_w = g->enc_node_w; k.g_node_b = g->enc_node_b; k.g_edge_w = g->enc_edge_w; k.g_edge_b = g->enc_edge_b;
+             k.g_w1 = g->enc_w1; k.g_b1 = g->enc_b1; k.g_w2 = g->enc_w2; k.g_b2 = g->enc_b2; }
+    k.ope = 1.0f + d.eps_enc; k.t = d.t_enc;
+    return k;
+}
+Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* g, const psvae_batch& b, const WS& w) {
+    Stack k{};
+    k.X = w.XD; k.A = w.AD; k.Hid = w.HD; k.Gr = w.GD; k.DH = w.DHD; k.DA = w.DAD;
+    k.rowptr = b.in_rowptr; k.col = b.in_col; k.etype = b.in_etype;
+    k.rowptr_t = b.in_rowptr_t; k.col_t = b.in_col_t; k.etype_t = b.in_etype_t;
+    k.node_w = p.dec_node_w; k.node_b = p.dec_node_b; k.edge_w = p.dec_edge_w; k.edge_b = p.dec_edge_b;
+    k.w1 = p.dec_w1; k.b1 = p.dec_b1; k.w2 = p.dec_w2; k.b2 = p.dec_b2;
+    if (g) { k.g_node_w = g->dec_node_w; k.g_node_b = g->dec_node_b; k.g_edge_w = g->dec_edge_w; k.g_edge_b = g->dec_edge_b;
+             k.g_w1 = g->dec_w1; k.g_b1 = g->dec_b1; k.g_w2 = g->dec_w2; k.g_b2 = g->dec_b2; }
+    k.ope = 1.0f + d.eps_dec; k.t = d.t_dec;
+    return k;
+}
+
+// Forward of 1 or 2 stacks with the same t: node_trans, then t x (aggregate, Linear+ReLU, Linear).
+int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng) {
+    const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
+    const int64_t dX = ng == 2 ? k[1].X - k[0].X : 0, dA = ng == 2 ? k[1].A - k[0].A : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
+    {   // slice 0 = node_trans(x0)
+        GemmDesc d;
+        d.A = w.X0; d.lda = s.Din; d.B = k[0].node_w; d.ldb = s.Din; d.C = k[0].X; d.ldc = ldx;
+        d.M = n; d.N = H; d.R = s.Din; d.bias = k[0].node_b; d.nseg = ng;
+        if (ng == 2) { d.seg_b = k[1].node_w - k[0].node_w; d.seg_bias = k[1].node_b - k[0].node_b; d.seg_c = dX; }
+        d.scratch = w.scratch; d.scratch_floats = w.scratch_floats;
+        PSVAE_TRY(gemm_f32(st, d));
+    }
+    for (int l = 0; l < t; ++l) {
+        AggGroup ag[2];
+        for (int q = 0; q < ng; ++q)
+            ag[q] = AggGroup{k[q].X + (size_t)l * H, k[q].A + (size_t)l * n * H, k[q].rowptr, k[q].col, k[q].etype,
+                             k[q].edge_w, k[q].edge_b, k[q].ope};
+        PSVAE_TRY(gine_agg_fwd(st, ag, ng, ldx, H, n, H));
+        GemmDesc d1;
+        d1.A = k[0].A + (size_t)l * n * H; d1.lda = H; d1.B = k[0].w1; d1.ldb = H; d1.C = k[0].Hid + (size_t)l * n * H; d1.ldc = H;
+        d1.M = n; d1.N = H; d1.R = H; d1.bias = k[0].b1; d1.relu = 1; d1.nseg = ng;
+        if (ng == 2) { d1.seg_a = dA; d1.seg_b = k[1].w1 - k[0].w1; d1.seg_bias = k[1].b1 - k[0].b1; d1.seg_c = dHid; }
+        d1.scratch = w.scratch; d1.scratch_floats = w.scratch_floats;
+        PSVAE_TRY(gemm_f32(st, d1));
+        GemmDesc d2;
+        d2.A = k[0].Hid + (size_t)l * n * H; d2.lda = H; d2.B = k[0].w2; d2.ldb = H; d2.C = k[0].X + (size_t)(l + 1) * H; d2.ldc = ldx;
+        d2.M = n; d2.N = H; d2.R = H; d2.bias = k[0].b2; d2.nseg = ng;
+        if (ng == 2) { d2.seg_a = dHid; d2.seg_b = k[1].w2 - k[0].w2; d2.seg_bias = k[1].b2 - k[0].b2; d2.seg_c = dX; }
+        d2.scratch = w.scratch; d2.scratch_floats = w.scratch_floats;
+        PSVAE_TRY(gemm_f32(st, d2));
+    }
+    return 0;
+}
+
+// Backward of 1 or 2 stacks with the same t.  On entry Gr slice t (= [n,H] block t of
+// Gr) holds dL/dx_t.  dpool[q] (or null) is the pooled-output gradient [B, t*H]
+// whose slice l-1 is broadcast into dL/dx_l.  Leaves dL/dx_0 of stack q in
+// w.G0[:, q*H:(q+1)*H] and writes the weight gradients of conv.nn and edge_trans.
+int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch& b, const Stack* k, int ng,
+                    const float* const* dpool, int g0_slot0) {
+    const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
+    const size_t nH = (size_t)n * H;
+    const int64_t dG = ng == 2 ? k[1].Gr - k[0].Gr : 0, dDH = ng == 2 ? k[1].DH - k[0].DH : 0;
+    const int64_t dDA = ng == 2 ? k[1].DA - k[0].DA : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
+    for (int l = t - 1; l >= 0; --l) {
+        GemmDesc d2;  // dHid_l = (G_{l+1} W2) * (Hid_l > 0)
+        d2.A = k[0].Gr + (size_t)(l + 1) * nH; d2.lda = H; d2.B = k[0].w2; d2.ldb = H; d2.b_t = true;
+        d2.C = k[0].DH + (size_t)l * nH; d2.ldc = H; d2.M = n; d2.N = H; d2.R = H;
+        d2.mask = k[0].Hid + (size_t)l * nH; d2.ldmask = H; d2.nseg = ng;
+        if (ng == 2) { d2.seg_a = dG; d2.seg_b = k[1].w2 - k[0].w2; d2.seg_c = dDH; d2.seg_mask = dHid; }
+        d2.scratch = w.scratch; d2.scratch_floats = w.scratch_floats;
+        PSVAE_TRY(gemm_f32(st, d2));
+        GemmDesc d1;  // dAgg_l = dHid_l W1
+        d1.A = k[0].DH + (size_t)l * nH; d1.lda = H; d1.B = k[0].w1; d1.ldb = H; d1.b_t = true;
+        d1.C = k[0].DA + (size_t)l * nH; d1.ldc = H; d1.M = n; d1.N = H; d1.R = H; d1.nseg = ng;
+        if (ng == 2) { d1.seg_a = dDH; d1.seg_b = k[1].w1 - k[0].w1; d1.seg_c = dDA; }
+        d1.scratch = w.scratch; d1.scratch_floats = w.scratch_floats;
+        PSVAE_TRY(gemm_f32(st, d1));
+        AggBwdGroup ag[2];
+        for (int q = 0; q < ng; ++q) {
+            float* dx = l > 0 ? k[q].Gr + (size_t)l * nH : w.G0 + (size_t)(g0_slot0 + q) * H;
+            const float* dp = (l > 0 && dpool && dpool[q]) ? dpool[q] + (size_t)(l - 1) * H : nullptr;
+            ag[q] = AggBwdGroup{k[q].DA + (size_t)l * nH, k[q].X + (size_t)l * H, dx, k[q].rowptr_t, k[q].col_t,
+                                k[q].etype_t, k[q].edge_w, k[q].edge_b, k[q].ope, dp};
+        }
+        PSVAE_TRY(gine_agg_bwd(st, ag, ng, H, ldx, l > 0 ? H : 2 * H, t * H, b.node_graph, n, H));
+    }
+    for (int q = 0; q < ng; ++q) {  // shared weights: sum over the t applications
+        PSVAE_TRY(linear_bwd_w(st, k[q].Gr + nH, H, (int64_t)nH, k[q].Hid, H, (int64_t)nH, t, k[q].g_w2, k[q].g_b2, n, H, H,
+                               w.scratch, w.scratch_floats));
+        PSVAE_TRY(linear_bwd_w(st, k[q].DH, H, (int64_t)nH, k[q].A, H, (int64_t)nH, t, k[q].g_w1, k[q].g_b1, n, H, H,
+                               w.scratch, w.scratch_floats));
+    }
+    EtabGroup eg[2];
+    const int chunks = etab_chunks(n);
+    const int tmax = s.te > s.td ? s.te : s.td;
+    for (int q = 0; q < ng; ++q)
+        eg[q] = EtabGroup{k[q].DA, (int64_t)nH, k[q].X, (int64_t)H, k[q].rowptr, k[q].col, k[q].etype, k[q].edge_w, k[q].edge_b,
+                          k[q].g_edge_w, k[q].g_edge_b, w.etab_part + (size_t)(g0_slot0 + q) * tmax * chunks * 4 * H};
+    PSVAE_TRY(gine_etab_grad(st, eg, ng, t, H, ldx, n, H, chunks));
+    return 0;
+}
+
+__global__ void split_mulv_kernel(const float* __restrict__ mulv, float* __restrict__ mean, float* __restrict__ lvar, int B, int Z) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * Z) return;
+    const int b = t / Z, k = t - b * Z;
+    mean[t] = mulv[(size_t)b * 2 * Z + k];
+    lvar[t] = -fabsf(mulv[(size_t)b * 2 * Z + Z + k]);
+}
+
+// Encoder half shared by the training step and psvae_encode: x0 .. mulv.
+int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, const psvae_batch& b, const Sz& s,
+                    const WS& w, bool with_decoder_stack) {
+    PSVAE_TRY(embed3_gather(st, b.atom_id, b.piece_id, b.pos_id, p.atom_emb, p.piece_emb, p.pos_emb, s.Da, s.Dp, s.Dq, w.X0, s.n));
+    Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
+    if (with_decoder_stack && s.te == s.td) {
+        PSVAE_TRY(stacks_forward(st, s, w, k, 2));
+    } else {
+        PSVAE_TRY(stacks_forward(st, s, w, &k[0], 1));
+        if (with_decoder_stack) PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1));
+    }
+    PSVAE_TRY(segment_pool_fwd(st, w.XE + s.H, (s.te + 1) * s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
+    PSVAE_TRY(linear_fwd(st, w.pooled, s.te * s.H, p.enc_lin_w, p.enc_lin_b, w.cond, s.G, s.B, s.G, s.te * s.H, 0,
+                         w.scratch, w.scratch_floats));
+    if (p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z) {
+        PSVAE_TRY(linear_fwd(st, w.cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, 0, w.scratch, w.scratch_floats));
+    } else {
+        PSVAE_TRY(linear_fwd(st, w.cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
+        PSVAE_TRY(linear_fwd(st, w.cond, s.G, p.lvar_w, p.lvar_b, w.mulv + s.Z, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t psvae_workspace_bytes(const psvae_dims* dims, const psvae_batch* bs) {
+    if (check_dims(dims, bs) != 0) return 0;
+    const Sz s = sizes(*dims, *bs);
+    return carve(s, nullptr, nullptr, nullptr, nullptr) * sizeof(float);
+}
+
+extern "C" int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_batch* bs, const char* name) {
+    if (check_dims(dims, bs) != 0 || !name) return -1;
+    const Sz s = sizes(*dims, *bs);
+    int64_t off = -1;
+    carve(s, nullptr, nullptr, name, &off);
+    return off;
+}
+
+extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                                  void* workspace, size_t workspace_bytes, float* losses, void* stream) {
+    PSVAE_TRY(check_dims(dims, batch));
+    if (!params || !workspace || !losses) return PSVAE_E_NULL;
+    if (!aligned16(workspace)) return PSVAE_E_ALIGN;
+    const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_batch& b = *batch;
+    const Sz s = sizes(d, b);
+    WS w;
+    if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+
+    PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true));
+    PSVAE_TRY(vae_head_fwd(st, w.mulv, b.eps, w.z, w.klrow, s.B, s.Z));
+    // property head (src/modules/predictor.py:19-21) + squared error rows
+    PSVAE_TRY(linear_fwd(st, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.q1, s.Hp, p.pred_w1, p.pred_b1, w.q2, s.Hp, s.B, s.Hp, s.Hp, 1, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.q2, s.Hp, p.pred_wo, p.pred_bo, w.pred, s.ldpred, s.B, s.NP, s.Hp, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(mse_fwd(st, w.pred, s.ldpred, b.props, w.mse_row, s.B, s.NP));
+    // piece branch (src/modules/vae_piece_decoder.py:81-90)
+    PSVAE_TRY(rows_gather(st, b.pieces, 0, s.T, s.L, p.piece_emb, s.Dp, w.semb, s.BT));
+    PSVAE_TRY(linear_fwd(st, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(gru_fwd(st, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R));
+    PSVAE_TRY(linear_fwd(st, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(softmax_ce_fwd(st, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
+    // link scorer (src/modules/vae_piece_decoder.py:97-110)
+    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
+    PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
+    PSVAE_TRY(losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, w.losses));
+    if (hipMemcpyAsync(losses, w.losses, 5 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+    return 0;
+}
+
+extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                                   void* workspace, size_t workspace_bytes, const float* loss_grads,
+                                   const psvae_params* grads, void* stream) {
+    PSVAE_TRY(check_dims(dims, batch));
+    if (!params || !workspace || !loss_grads || !grads) return PSVAE_E_NULL;
+    const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_params& g = *grads; const psvae_batch& b = *batch;
+    const Sz s = sizes(d, b);
+    WS w;
+    if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const float* gs = loss_grads;  // [pred, piece, edge, kl]
+    float* sc = w.scratch; const size_t scf = w.scratch_floats;
+
+    // --- property head
+    PSVAE_TRY(mse_bwd(st, w.pred, s.ldpred, b.props, gs, b.denoms, w.dpred, s.B, s.NP));
+    PSVAE_TRY(linear_bwd_w(st, w.dpred, s.ldpred, 0, w.q2, s.Hp, 0, 1, g.pred_wo, g.pred_bo, s.B, s.NP, s.Hp, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.dpred, s.ldpred, p.pred_wo, w.dq2, s.Hp, s.B, s.NP, s.Hp, w.q2, s.Hp, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.dq2, s.Hp, 0, w.q1, s.Hp, 0, 1, g.pred_w1, g.pred_b1, s.B, s.Hp, s.Hp, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.dq2, s.Hp, p.pred_w1, w.dq1, s.Hp, s.B, s.Hp, s.Hp, w.q1, s.Hp, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.dq1, s.Hp, 0, w.z, s.Z, 0, 1, g.pred_w0, g.pred_b0, s.B, s.Hp, s.Z, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.dq1, s.Hp, p.pred_w0, w.dz, s.Z, s.B, s.Hp, s.Z, nullptr, 0, 0));
+    // --- piece branch
+    PSVAE_TRY(softmax_ce_bwd(st, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.logits, s.ldl, 0, w.hseq, s.R, 0, 1, g.vocab_w, g.vocab_b, s.BT, s.V2, s.R, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
+    PSVAE_TRY(gru_bwd(st, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R));
+    PSVAE_TRY(linear_bwd_w(st, w.dgh, 3 * s.R, 0, w.hprev, s.R, 0, 1, g.gru_whh, g.gru_bhh, s.BT, 3 * s.R, s.R, sc, scf));
+    PSVAE_TRY(linear_bwd_w(st, w.dgi, 3 * s.R, 0, w.semb, s.Dp, 0, 1, g.gru_wih, g.gru_bih, s.BT, 3 * s.R, s.Dp, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.dh0, s.R, 0, w.z, s.Z, 0, 1, g.l2h_w, g.l2h_b, s.B, s.R, s.Z, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.dh0, s.R, p.l2h_w, w.dz, s.Z, s.B, s.R, s.Z, nullptr, 0, 1));
+    // --- link scorer
+    PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
+    PSVAE_TRY(linear_bwd_w(st, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.ds3, s.P, p.sc_w2, w.ds2, s.P2, s.S, s.P, s.P2, w.s2, s.P2, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.ds2, s.P2, 0, w.s1, s.P2, 0, 1, g.sc_w1, g.sc_b1, s.S, s.P2, s.P2, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.ds2, s.P2, p.sc_w1, w.ds1, s.P2, s.S, s.P2, s.P2, w.s1, s.P2, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.ds1, s.P2, p.sc_w0, w.dpin, s.P, s.S, s.P2, s.P, nullptr, 0, 0));
+    const size_t nH = (size_t)s.n * s.H;
+    PSVAE_TRY(pair_scatter(st, w.dpin, s.P, b.pair_by_src_ptr, b.pair_by_src_idx, b.pair_by_dst_ptr, b.pair_by_dst_idx,
+                           b.pair_graph_off, w.GD + (size_t)s.td * nH, s.H, w.dz, 1, s.n, s.B, s.H, s.Z));
+    // --- latent head and encoder.linear
+    PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz, gs, b.denoms, w.dmulv, s.B, s.Z));
+    const bool head_adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z &&
+                               g.lvar_w == g.mean_w + (size_t)s.Z * s.G && g.lvar_b == g.mean_b + s.Z;
+    if (head_adjacent) {
+        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, w.cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, w.dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
+    } else {
+        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, w.cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_w(st, w.dmulv + s.Z, 2 * s.Z, 0, w.cond, s.G, 0, 1, g.lvar_w, g.lvar_b, s.B, s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, w.dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_x(st, w.dmulv + s.Z, 2 * s.Z, p.lvar_w, w.dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 1));
+    }
+    const int TH = s.te * s.H;
+    PSVAE_TRY(linear_bwd_w(st, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
+    // --- GINE stacks: dL/dx_te of the encoder is the broadcast of the last pooled slice
+    Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
+    {
+        AggBwdGroup top{nullptr, nullptr, w.GE + (size_t)s.te * nH, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f,
+                        w.dpooled + (size_t)(s.te - 1) * s.H};
+        PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
+    }
+    const float* dpool[2] = {w.dpooled, nullptr};
+    if (s.te == s.td) {
+        PSVAE_TRY(stacks_backward(st, s, w, b, k, 2, dpool, 0));
+    } else {
+        PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0));
+        PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1));
+    }
+    // --- node_trans of both stacks from G0 = [dL/dx0_enc | dL/dx0_dec]  ([n, 2H])
+    const bool node_adjacent = p.dec_node_w == p.enc_node_w + (size_t)s.H * s.Din && g.dec_node_w == g.enc_node_w + (size_t)s.H * s.Din &&
+                               g.dec_node_b == g.enc_node_b + s.H;
+    if (node_adjacent) {
+        PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, 2 * s.H, s.Din, sc, scf));
+        PSVAE_TRY(linear_bwd_x(st, w.G0, 2 * s.H, p.enc_node_w, w.dX0, s.Din, s.n, 2 * s.H, s.Din, nullptr, 0, 0));
+    } else {
+        PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, s.H, s.Din, sc, scf));
+        PSVAE_TRY(linear_bwd_w(st, w.G0 + s.H, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.dec_node_w, g.dec_node_b, s.n, s.H, s.Din, sc, scf));
+        PSVAE_TRY(linear_bwd_x(st, w.G0, 2 * s.H, p.enc_node_w, w.dX0, s.Din, s.n, s.H, s.Din, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_x(st, w.G0 + s.H, 2 * s.H, p.dec_node_w, w.dX0, s.Din, s.n, s.H, s.Din, nullptr, 0, 1));
+    }
+    // --- embedding tables (piece table also receives the GRU-input gradient)
+    PSVAE_TRY(table_grad(st, g.atom_emb, d.num_atom, s.Da, b.atom_rows_ptr, b.atom_rows_idx, w.dX0, s.Din, 0,
+                         nullptr, nullptr, nullptr, 0, 0));
+    PSVAE_TRY(table_grad(st, g.piece_emb, d.num_piece, s.Dp, b.piece_rows_ptr, b.piece_rows_idx, w.dX0, s.Din, s.Da,
+                         b.seq_rows_ptr, b.seq_rows_idx, w.dsemb, s.Dp, 0));
+    PSVAE_TRY(table_grad(st, g.pos_emb, d.max_pos, s.Dq, b.pos_rows_ptr, b.pos_rows_idx, w.dX0, s.Din, s.Da + s.Dp,
+                         nullptr, nullptr, nullptr, 0, 0));
+    return 0;
+}
+
+extern "C" int psvae_encode(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                            void* workspace, size_t workspace_bytes, float* z_mean, float* z_log_var, void* stream) {
+    PSVAE_TRY(check_dims(dims, batch));
+    if (!params || !workspace || !z_mean || !z_log_var) return PSVAE_E_NULL;
+    const Sz s = sizes(*dims, *batch);
+    WS w;
+    if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    PSVAE_TRY(encoder_to_mulv(st, *dims, *params, *batch, s, w, false));
+    hipLaunchKernelGGL(split_mulv_kernel, dim3((s.B * s.Z + 255) / 256), dim3(256), 0, st, w.mulv, z_mean, z_log_var, s.B, s.Z);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}

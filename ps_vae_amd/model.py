@@ -1,0 +1,323 @@
+"""PSVAEModel: the reference's model surface (`src/pl_models/ps_vae_model.py`)
+driving the fused HIP training step.
+
+All parameters live in ONE flat fp32 buffer (each nn.Parameter is a view into
+it); gradients live in a second flat buffer of the same layout.  The flat
+buffers are what the fused optimiser updates and what data-parallel training
+all-reduces, and their order groups parameters by the moment their gradient is
+final during backward.  `state_dict()` / `load_state_dict()` keep the
+reference's keys and shapes.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .data import ensure_native
+from .modules import Encoder, Predictor, VAEPieceDecoder
+
+# flat-buffer order: buckets in the order backward finishes them
+FLAT_ORDER = [
+    # bucket 0: property head, piece branch
+    'predictor.mlp.0.weight', 'predictor.mlp.0.bias', 'predictor.mlp.2.weight', 'predictor.mlp.2.bias',
+    'predictor.output.weight', 'predictor.output.bias', 'decoder.to_vocab.weight', 'decoder.to_vocab.bias',
+    'decoder.rnn.weight_ih_l0', 'decoder.rnn.weight_hh_l0', 'decoder.rnn.bias_ih_l0', 'decoder.rnn.bias_hh_l0',
+    'decoder.latent_to_rnn_hidden.weight', 'decoder.latent_to_rnn_hidden.bias',
+    # bucket 1: link scorer
+    'decoder.edge_predictor.0.seq.0.weight', 'decoder.edge_predictor.0.seq.0.bias',
+    'decoder.edge_predictor.0.seq.2.weight', 'decoder.edge_predictor.0.seq.2.bias',
+    'decoder.edge_predictor.0.seq.4.weight', 'decoder.edge_predictor.0.seq.4.bias',
+    'decoder.edge_predictor.1.weight', 'decoder.edge_predictor.1.bias',
+    # bucket 2: latent head (mean | log-var kept adjacent), encoder.linear
+    'decoder.W_mean.weight', 'decoder.W_log_var.weight', 'decoder.W_mean.bias', 'decoder.W_log_var.bias',
+    'encoder.linear.weight', 'encoder.linear.bias',
+    # bucket 3: both GINE stacks (node_trans of the two stacks kept adjacent), embedding tables
+    'encoder.conv.nn.seq.0.weight', 'encoder.conv.nn.seq.0.bias', 'encoder.conv.nn.seq.2.weight', 'encoder.conv.nn.seq.2.bias',
+    'decoder.graph_embedding.conv.nn.seq.0.weight', 'decoder.graph_embedding.conv.nn.seq.0.bias',
+    'decoder.graph_embedding.conv.nn.seq.2.weight', 'decoder.graph_embedding.conv.nn.seq.2.bias',
+    'encoder.edge_trans.weight', 'encoder.edge_trans.bias',
+    'decoder.graph_embedding.edge_trans.weight', 'decoder.graph_embedding.edge_trans.bias',
+    'encoder.node_trans.weight', 'decoder.graph_embedding.node_trans.weight',
+    'encoder.node_trans.bias', 'decoder.graph_embedding.node_trans.bias',
+    'decoder.atom_embedding.weight', 'decoder.piece_embedding.weight', 'decoder.pos_embedding.weight',
+]
+BUCKET_STARTS = ['predictor.mlp.0.weight', 'decoder.edge_predictor.0.seq.0.weight', 'decoder.W_mean.weight',
+                 'encoder.conv.nn.seq.0.weight']
+# never used by the training step (the decoder-side encoder's `linear`): no gradient, not optimised
+UNTRAINED = ['decoder.graph_embedding.linear.weight', 'decoder.graph_embedding.linear.bias']
+
+
+class _StepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, trigger, model, nb, eps):
+        L = _lib.lib()
+        dims, params = model._dims, model._params_struct
+        bs = nb.struct(eps)
+        nbytes = L.psvae_workspace_bytes(C.byref(dims), C.byref(bs))
+        if nbytes == 0:
+            raise RuntimeError('psvae_workspace_bytes rejected the model/batch sizes (hidden, latent and rnn sizes '
+                               'must be multiples of 4; 4 bond types)')
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=eps.device)
+        losses = torch.empty(5, dtype=torch.float32, device=eps.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.psvae_step_forward(C.byref(dims), C.byref(params), C.byref(bs), ws.data_ptr(), nbytes,
+                                        losses.data_ptr(), stream), 'psvae_step_forward')
+        ctx.model, ctx.nb, ctx.eps, ctx.ws, ctx.nbytes = model, nb, eps, ws, nbytes
+        model._last_ws = (ws, nb)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        model, nb = ctx.model, ctx.nb
+        # upstream gradients of (pred, piece, edge, kl); rec = piece + edge feeds both
+        gs = torch.stack([g[0], g[2] + g[1], g[3] + g[1], g[4]]).contiguous()
+        grads_struct, fresh = model._grad_target()
+        bs = nb.struct(ctx.eps)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.psvae_step_backward(C.byref(model._dims), C.byref(model._params_struct), C.byref(bs),
+                                         ctx.ws.data_ptr(), ctx.nbytes, gs.data_ptr(), C.byref(grads_struct), stream),
+                   'psvae_step_backward')
+        model._grad_written(fresh)
+        ctx.ws = None
+        return g.new_zeros(()), None, None, None
+
+
+class PSVAEModel(nn.Module):
+    """`PSVAEModel(config, tokenizer)` with `.forward(batch, return_accu=False)`,
+    `.weighted_loss`, `.cal_beta`, `.get_z`, `.sample_z`, `.predict_props`
+    (`src/pl_models/ps_vae_model.py:18-74,130-170`).  `global_step` is advanced by
+    the training loop (Lightning did it for the reference)."""
+
+    def __init__(self, config, tokenizer):
+        super().__init__()
+        self.config = config
+        self.tokenizer = tokenizer
+        self.chem_vocab = tokenizer.chem_vocab
+        self.predictor = Predictor(**config['predictor'])
+        self.encoder = Encoder(**config['encoder'])
+        self.decoder = VAEPieceDecoder(**config['vae_piece_decoder'])
+        self.global_step = 0
+        self.total_time = 0
+        self._flat = self._gflat = self._gtmp = None
+        self._grads_fresh = True
+        self._trigger = None
+        self._last_ws = None
+        self._dims = self._make_dims()
+
+    # ------------------------------------------------------------------ layout
+    def _make_dims(self):
+        dec, enc, cfg = self.decoder, self.encoder, self.config
+        d = _lib.Dims()
+        d.num_piece, d.num_atom, d.num_bond = self.tokenizer.num_piece_type(), self.tokenizer.num_atom_type(), enc.num_edge_type
+        d.max_pos = dec.pos_embedding.num_embeddings
+        d.d_atom, d.d_piece, d.d_pos = (dec.atom_embedding.embedding_dim, dec.piece_embedding.embedding_dim,
+                                        dec.pos_embedding.embedding_dim)
+        d.hidden, d.graph = enc.node_trans.out_features, enc.linear.out_features
+        d.latent, d.rnn = dec.latent_dim, dec.rnn.hidden_size
+        d.pred_hidden, d.n_props = self.predictor.output.in_features, self.predictor.output.out_features
+        d.t_enc, d.t_dec = enc.t, dec.graph_embedding.t
+        d.pad_idx = self.tokenizer.pad_idx()
+        d.eps_enc, d.eps_dec = float(enc.conv.eps), float(dec.graph_embedding.conv.eps)
+        if dec.graph_embedding.node_trans.out_features != d.hidden:
+            raise ValueError('encoder and decoder node hidden sizes must match (as the reference CLI builds them)')
+        return d
+
+    def _flatten(self):
+        """(Re)build the flat parameter / gradient buffers on the parameters' device."""
+        named = dict(self.named_parameters())
+        order = FLAT_ORDER + UNTRAINED
+        assert sorted(order) == sorted(named.keys()), 'parameter set differs from the reference state-dict'
+        dev = named[order[0]].device
+        offs, off = {}, 0
+        for k in order:
+            if k == UNTRAINED[0]:
+                self._n_trained = off
+            offs[k] = off
+            off += (named[k].numel() + 3) // 4 * 4
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(self._n_trained, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for k in order:
+                p = named[k]
+                view = flat[offs[k]:offs[k] + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                if k not in UNTRAINED:
+                    p.grad = gflat[offs[k]:offs[k] + p.numel()].view(p.shape)
+        self._flat, self._gflat, self._gtmp, self._offsets = flat, gflat, None, offs
+        self._grads_fresh = True
+        self._params_struct = self._struct_over(flat)
+        self._grads_struct = self._struct_over(gflat)
+        self._trigger = torch.zeros((), device=dev, requires_grad=True)
+        self._dims = self._make_dims()
+        self.bucket_bounds = [offs[k] for k in BUCKET_STARTS] + [self._n_trained]
+
+    def _struct_over(self, buf):
+        named = dict(self.named_parameters())
+        s = _lib.Params()
+        base = buf.data_ptr()
+        for field, key in _lib.PARAM_KEYS.items():
+            setattr(s, field, base + 4 * self._offsets[key])
+            assert named[key].numel() > 0
+        return s
+
+    def _sync_flat(self):
+        p0 = self.predictor.mlp[0].weight
+        if (self._flat is None or p0.device != self._flat.device or
+                p0.data_ptr() != self._flat.data_ptr() + 4 * self._offsets['predictor.mlp.0.weight']):
+            self._flatten()
+        elif p0.grad is None:
+            named = dict(self.named_parameters())
+            for k in FLAT_ORDER:
+                p = named[k]
+                p.grad = self._gflat[self._offsets[k]:self._offsets[k] + p.numel()].view(p.shape)
+            self._gflat.zero_()
+            self._grads_fresh = True
+
+    def flat_buffers(self):
+        """(parameters, gradients) as flat fp32 tensors over the trained range."""
+        self._sync_flat()
+        return self._flat[:self._n_trained], self._gflat
+
+    def zero_grad(self, set_to_none=False):
+        """Marks the flat gradient buffer as empty: the next backward overwrites it
+        (no separate zero-fill pass is needed)."""
+        self._grads_fresh = True
+
+    def _grad_target(self):
+        if self._grads_fresh:
+            return self._grads_struct, True
+        if self._gtmp is None:
+            self._gtmp = torch.empty_like(self._gflat)
+            self._gtmp_struct = self._struct_over(self._gtmp)
+        return self._gtmp_struct, False
+
+    def _grad_written(self, fresh):
+        if not fresh:
+            self._gflat.add_(self._gtmp)   # gradient accumulation across backward calls
+        self._grads_fresh = False
+
+    # ------------------------------------------------------------------ forward
+    def _native(self, batch):
+        nb = ensure_native(batch, self.tokenizer, tuple(self.config['selected_properties']),
+                           self.decoder.pos_embedding.num_embeddings)
+        dev = self._flat.device
+        if nb.device != dev:
+            nb = nb.to(dev)
+            batch['_native'] = nb
+        return nb
+
+    def forward(self, batch, return_accu=False, eps=None):
+        """Returns `(pred_loss, (rec, piece, edge, kl))`, or with `return_accu`
+        `(pred_loss, ((rec, piece, edge, kl), (piece_accu, edge_accu)))`.
+        `eps` [B, latent] optionally replaces the N(0,1) draw of `rsample`."""
+        self._sync_flat()
+        if not self._flat.is_cuda:
+            raise RuntimeError('PSVAEModel runs on the GPU only: move it with .cuda() (no CPU implementation exists)')
+        nb = self._native(batch)
+        B = nb.sizes['B']
+        if eps is None:
+            eps = torch.randn(B, self._dims.latent, dtype=torch.float32, device=self._flat.device)
+        eps = eps.to(self._flat.device, torch.float32).contiguous()
+        out = _StepFn.apply(self._trigger, self, nb, eps)
+        pred_loss, losses = out[0], (out[1], out[2], out[3], out[4])
+        if return_accu:
+            return pred_loss, (losses, self._accuracies(nb))
+        return pred_loss, losses
+
+    def _ws_view(self, name, rows, cols, ld=None):
+        ws, nb = self._last_ws
+        L = _lib.lib()
+        off = L.psvae_workspace_offset(C.byref(self._dims), C.byref(nb.struct()), name.encode())
+        if off < 0:
+            raise KeyError(name)
+        ld = cols if ld is None else ld
+        flat = ws.view(torch.float32)
+        return flat[off:off + rows * ld].view(rows, ld)[:, :cols]
+
+    def _accuracies(self, nb):
+        """`src/modules/vae_piece_decoder.py:120-124`."""
+        B, L, S, V2 = nb.sizes['B'], nb.sizes['L'], nb.sizes['S'], self._dims.num_piece
+        T = L - 1
+        logits = self._ws_view('logits', B * T, V2, (V2 + 3) // 4 * 4)
+        off = nb.offsets[_lib.BLOB_FIELDS.index('pieces')]
+        gold = nb.blob[off:off + B * L].view(B, L)[:, 1:].reshape(-1).long()
+        not_pad = gold != self.tokenizer.pad_idx()
+        piece_accu = ((logits.argmax(-1) == gold) & not_pad).sum().item() / not_pad.sum().item()
+        pair_logits = self._ws_view('pair_logits', S, 4)
+        goff = nb.offsets[_lib.BLOB_FIELDS.index('pair_gold')]
+        golden = nb.blob[goff:goff + S].long()
+        edge_accu = (pair_logits.argmax(-1) == golden).sum().item() / max(S, 1)
+        return piece_accu, edge_accu
+
+    def activation(self, name, rows, cols, ld=None):
+        """View of a saved activation of the most recent forward (tests, debugging)."""
+        return self._ws_view(name, rows, cols, ld)
+
+    def cal_beta(self):
+        step, cfg = self.global_step, self.config
+        if step < cfg['kl_warmup']:
+            beta = 0
+        else:
+            beta = min(cfg['max_beta'], ((step - cfg['kl_warmup']) // cfg['kl_anneal_iter'] + 1) * cfg['step_beta'])
+        return beta + cfg['beta']
+
+    def weighted_loss(self, pred_loss, rec_loss, kl_loss):
+        alpha = self.config['alpha']
+        return alpha * rec_loss + (1 - alpha) * pred_loss + self.cal_beta() * kl_loss
+
+    def training_step(self, batch, batch_idx=0, eps=None):
+        pred_loss, rec_losses = self.forward(batch, eps=eps)
+        return self.weighted_loss(pred_loss, rec_losses[0], rec_losses[-1])
+
+    def configure_optimizers(self):
+        from .optim import FusedClipAdam
+        return FusedClipAdam(self, lr=self.config['lr'])
+
+    # ------------------------------------------------------------------ interface
+    def encode(self, batch):
+        """Deterministic encoder output: (z_mean, z_log_var), each [B, latent]."""
+        self._sync_flat()
+        if not self._flat.is_cuda:
+            raise RuntimeError('PSVAEModel runs on the GPU only (no CPU implementation exists)')
+        L = _lib.lib()
+        nb = self._native(batch)
+        bs = nb.struct()
+        nbytes = L.psvae_workspace_bytes(C.byref(self._dims), C.byref(bs))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
+        B, Z = nb.sizes['B'], self._dims.latent
+        mean = torch.empty(B, Z, dtype=torch.float32, device=self._flat.device)
+        lvar = torch.empty_like(mean)
+        _lib.check(L.psvae_encode(C.byref(self._dims), C.byref(self._params_struct), C.byref(bs), ws.data_ptr(), nbytes,
+                                  mean.data_ptr(), lvar.data_ptr(), torch.cuda.current_stream().cuda_stream), 'psvae_encode')
+        return mean, lvar
+
+    def get_z(self, batch, eps=None):
+        """`ps_vae_model.py:160-170`: a sample z = mean + exp(log_var / 2) * eps."""
+        with torch.no_grad():
+            mean, lvar = self.encode(batch)
+            eps = torch.randn_like(mean) if eps is None else eps.to(mean.device)
+            return mean + torch.exp(lvar / 2) * eps
+
+    def sample_z(self, n, device=None):
+        return torch.randn(n, self.decoder.latent_dim, device=device if device is not None else self._flat.device)
+
+    def predict_props(self, z):
+        props = self.predictor(z)
+        idx = self.config['selected_properties']
+        if props.dim() == 1:
+            out = torch.zeros(3, device=props.device)
+            out[idx] = props
+            return out
+        out = torch.zeros(props.shape[0], 3, device=props.device)
+        out[:, idx] = props
+        return out
+
+    def get_from_batch(self, batch, key):
+        if key == 'batch_size':
+            return batch['x'].shape[0]
+        if key == 'props':
+            return batch['props']
+        raise KeyError(key)

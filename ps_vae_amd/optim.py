@@ -1,0 +1,56 @@
+"""Fused global-norm clip + Adam over the model's flat buffers: the semantics of
+`clip_grad_norm_(params, 10.0)` (`src/train.py:47`) followed by
+`torch.optim.Adam(lr)` with the per-epoch `lr / (epoch + 1)` schedule
+(`src/pl_models/ps_vae_model.py:123-127`), as two kernel launches and no host
+synchronisation."""
+import torch
+
+from . import _lib
+
+
+class FusedClipAdam:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0):
+        self.model, self.base_lr, self.betas, self.eps, self.max_norm = model, lr, betas, eps, max_norm
+        self.epoch = 0
+        self.step_count = 0
+        self.exp_avg = self.exp_avg_sq = self.partials = self.grad_norm = None
+
+    @property
+    def lr(self):
+        return self.base_lr / (self.epoch + 1)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def zero_grad(self, set_to_none=False):
+        self.model.zero_grad()
+
+    def _state(self, params):
+        if self.exp_avg is None or self.exp_avg.device != params.device or self.exp_avg.numel() != params.numel():
+            L = _lib.lib()
+            self.exp_avg = torch.zeros_like(params)
+            self.exp_avg_sq = torch.zeros_like(params)
+            self.partials = torch.zeros(L.psvae_adam_partials(params.numel()), dtype=torch.float32, device=params.device)
+            self.grad_norm = torch.zeros(1, dtype=torch.float32, device=params.device)
+
+    def step(self):
+        L = _lib.lib()
+        params, grads = self.model.flat_buffers()
+        if not params.is_cuda:
+            raise RuntimeError('FusedClipAdam runs on the GPU only')
+        self._state(params)
+        self.step_count += 1
+        b1, b2 = self.betas
+        bias1, bias2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        _lib.check(L.psvae_clip_adam(params.data_ptr(), grads.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), params.numel(), self.partials.data_ptr(),
+                                     self.max_norm, self.lr, b1, b2, self.eps, bias1, bias2, self.grad_norm.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), 'psvae_clip_adam')
+        self.model.zero_grad()
+
+    def state_dict(self):
+        return {'step': self.step_count, 'epoch': self.epoch, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+
+    def load_state_dict(self, sd):
+        self.step_count, self.epoch = sd['step'], sd['epoch']
+        self.exp_avg, self.exp_avg_sq = sd['exp_avg'], sd['exp_avg_sq']

@@ -1,0 +1,198 @@
+"""Single HIP operators (through the C ABI) against plain fp32 torch on the CPU.
+Tolerance: rtol 1e-4 with an absolute floor scaled to the tensor (tests/util.py)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import check_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize('M,N,K,relu', [
+    (2964, 300, 200, False), (2964, 300, 300, True), (128, 400, 1200, False), (128, 112, 400, False),
+    (1, 5, 7, True), (67, 42, 16, False), (3000, 4, 656, False), (1408, 302, 200, False), (130, 66, 130, True),
+])
+def test_linear_forward_backward(M, N, K, relu):
+    from ps_vae_amd import ops
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1)
+    dy = _rand(M, N, seed=4)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.linear(xr, wr, br)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy)
+    xg, wg, bg = (t.to(dev()).requires_grad_() for t in (x, w, b))
+    y = ops.linear(xg, wg, bg, relu=relu)
+    y.backward(dy.to(dev()))
+    check_close(y, yr, 'y')
+    check_close(xg.grad, xr.grad, 'dx')
+    check_close(wg.grad, wr.grad, 'dw')
+    check_close(bg.grad, br.grad, 'db')
+
+
+def test_linear_strided_mask_accumulate_and_segments():
+    """The C entry points directly: leading dimensions, ReLU-mask epilogue, accumulation, summed segments."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    M, N, K, t = 333, 300, 300, 4
+    dy_all = _rand(t, M, N, seed=5)
+    x_all = _rand(t, M, K, seed=6)
+    w = _rand(N, K, seed=7, scale=0.05)
+    mask = _rand(M, K, seed=8)
+    prev = _rand(M, 2 * K, seed=9)
+    # dx written into a [M, 2K] buffer at column offset K with mask and accumulate
+    d_dy, d_w, d_mask, d_prev = dy_all[0].to(dev()), w.to(dev()), mask.to(dev()), prev.to(dev())
+    _lib.check(L.psvae_linear_backward_input(d_dy.data_ptr(), N, d_w.data_ptr(), d_prev.data_ptr() + 4 * K, 2 * K,
+                                             M, N, K, d_mask.data_ptr(), K, 1, st))
+    want = prev.clone()
+    want[:, K:] += (dy_all[0] @ w) * (mask > 0)
+    check_close(d_prev, want, 'dx strided/masked/accumulated')
+    # dw summed over t segments + bias gradient
+    d_dyall, d_xall = dy_all.to(dev()), x_all.to(dev())
+    dw = torch.empty(N, K, device=dev())
+    db = torch.empty(N, device=dev())
+    nbytes = L.psvae_linear_scratch_bytes(M, N, K, t)
+    sc = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    _lib.check(L.psvae_linear_backward_weight(d_dyall.data_ptr(), N, M * N, d_xall.data_ptr(), K, M * K, t, dw.data_ptr(),
+                                              db.data_ptr(), M, N, K, sc.data_ptr(), nbytes, st))
+    check_close(dw, sum(dy_all[i].t() @ x_all[i] for i in range(t)), 'dw over segments')
+    check_close(db, dy_all.sum((0, 1)), 'db over segments')
+
+
+def _random_graph(n, E, seed):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, E), generator=g)
+    et = torch.randint(1, 4, (E,), generator=g)
+    return ei, et
+
+
+@pytest.mark.parametrize('n,E,H', [(500, 1100, 300), (64, 0, 20), (1, 3, 8), (2000, 9000, 512)])
+def test_gine_aggregate_forward_backward(n, E, H):
+    from ps_vae_amd import ops
+    ei, et = _random_graph(n, E, seed=n)
+    x, ew, eb = _rand(n, H, seed=1), _rand(H, 4, seed=2), _rand(H, seed=3, scale=0.1)
+    dout = _rand(n, H, seed=4)
+    xr, ewr, ebr = x.clone().requires_grad_(), ew.clone().requires_grad_(), eb.clone().requires_grad_()
+    e = F.linear(F.one_hot(et, 4).float(), ewr, ebr)
+    msg = torch.relu(xr.index_select(0, ei[0]) + e)
+    ref = torch.zeros_like(xr).index_add_(0, ei[1], msg) + 1.25 * xr
+    ref.backward(dout)
+    xg, ewg, ebg = (t.to(dev()).requires_grad_() for t in (x, ew, eb))
+    csr = ops.Csr(ei.to(dev()), et.to(dev()), n)
+    out = ops.GineAggregateFn.apply(xg, ewg, ebg, csr, 1.25)
+    out.backward(dout.to(dev()))
+    check_close(out, ref, 'aggregate')
+    check_close(xg.grad, xr.grad, 'dx')
+    check_close(ewg.grad, ewr.grad if E else torch.zeros_like(ew), 'd edge_w')
+    check_close(ebg.grad, ebr.grad if E else torch.zeros_like(eb), 'd edge_b')
+
+
+def test_segment_pool_forward_backward():
+    from ps_vae_amd import ops
+    lens = torch.tensor([3, 1, 7, 38, 12, 1])
+    off = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    n, W = int(off[-1]), 1200
+    gid = torch.repeat_interleave(torch.arange(len(lens)), lens)
+    x = _rand(n, W, seed=1)
+    dp = _rand(len(lens), W, seed=2)
+    xr = x.clone().requires_grad_()
+    ref = torch.zeros(len(lens), W).index_add_(0, gid, xr)
+    ref.backward(dp)
+    xg = x.to(dev()).requires_grad_()
+    out = ops.SegmentPoolFn.apply(xg, off.to(torch.int32).to(dev()), gid.to(torch.int32).to(dev()))
+    out.backward(dp.to(dev()))
+    check_close(out, ref, 'pooled')
+    check_close(xg.grad, xr.grad, 'dx')
+
+
+@pytest.mark.parametrize('B,T,R', [(128, 11, 200), (5, 3, 16), (33, 1, 20), (16, 7, 64)])
+def test_gru_forward_backward(B, T, R):
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gi, h0 = _rand(B, T, 3 * R, seed=1), _rand(B, R, seed=2)
+    whh, bhh = _rand(3 * R, R, seed=3, scale=R ** -0.5), _rand(3 * R, seed=4, scale=0.1)
+    dh = _rand(B, T, R, seed=5)
+    gir, h0r, whr, bhr = (t.clone().requires_grad_() for t in (gi, h0, whh, bhh))
+    h, outs = h0r, []
+    for t in range(T):
+        gh = F.linear(h, whr, bhr)
+        r = torch.sigmoid(gir[:, t, :R] + gh[:, :R])
+        u = torch.sigmoid(gir[:, t, R:2 * R] + gh[:, R:2 * R])
+        c = torch.tanh(gir[:, t, 2 * R:] + r * gh[:, 2 * R:])
+        h = (1 - u) * c + u * h
+        outs.append(h)
+    ref = torch.stack(outs, 1)
+    ref.backward(dh)
+    d = dev()
+    g_gi, g_h0, g_whh, g_bhh, g_dh = (t.to(d).contiguous() for t in (gi, h0, whh, bhh, dh))
+    hseq, hprev = torch.empty(B * T, R, device=d), torch.empty(B * T, R, device=d)
+    gates = torch.empty(B * T, 4 * R, device=d)
+    _lib.check(L.psvae_gru_forward(g_gi.data_ptr(), g_h0.data_ptr(), g_whh.data_ptr(), g_bhh.data_ptr(), hseq.data_ptr(),
+                                   hprev.data_ptr(), gates.data_ptr(), B, T, R, st))
+    check_close(hseq.view(B, T, R), ref, 'gru output')
+    dgi, dgh, dh0 = torch.empty(B * T, 3 * R, device=d), torch.empty(B * T, 3 * R, device=d), torch.empty(B, R, device=d)
+    _lib.check(L.psvae_gru_backward(g_dh.data_ptr(), hprev.data_ptr(), gates.data_ptr(), g_whh.data_ptr(), dgi.data_ptr(),
+                                    dgh.data_ptr(), dh0.data_ptr(), B, T, R, st))
+    check_close(dgi.view(B, T, 3 * R), gir.grad, 'd gi')
+    check_close(dh0, h0r.grad, 'd h0')
+    check_close(dgh.view(B * T, 3 * R).t().cpu() @ hprev.cpu(), whr.grad, 'd whh (from dgh, hprev)')
+    check_close(dgh.sum(0), bhr.grad, 'd bhh')
+
+
+def test_softmax_ce_rows():
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, Lseq, V2, pad = 9, 6, 302, 300
+    T = Lseq - 1
+    logits = _rand(B * T, 304, seed=1, scale=4.0)
+    g = torch.Generator().manual_seed(2)
+    pieces = torch.randint(0, V2, (B, Lseq), generator=g)
+    pieces[2, 3:] = pad
+    pieces[5, 1:] = pad
+    d = dev()
+    row, lse = torch.empty(B * T, device=d), torch.empty(B * T, device=d)
+    lg, pc = logits.to(d), pieces.to(torch.int32).to(d)
+    _lib.check(L.psvae_softmax_ce_forward(lg.data_ptr(), 304, pc.data_ptr(), Lseq, 1, T, B * T, V2, pad, row.data_ptr(),
+                                          lse.data_ptr(), st))
+    gold = pieces[:, 1:].reshape(-1)
+    want = F.cross_entropy(logits[:, :V2], gold, ignore_index=pad, reduction='none')
+    check_close(row, want, 'row losses')
+    check_close(lse, torch.logsumexp(logits[:, :V2], -1), 'lse')
+
+
+def test_clip_adam_matches_torch():
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    n = 100003
+    p0, g0 = _rand(n, seed=1), _rand(n, seed=2, scale=0.2)   # norm ~ 36 > 10 -> clipping active
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    d = dev()
+    p, m, v = p0.to(d), torch.zeros(n, device=d), torch.zeros(n, device=d)
+    part = torch.zeros(L.psvae_adam_partials(n), device=d)
+    norm = torch.zeros(1, device=d)
+    for step in range(1, 4):
+        gr = g0 * step
+        pr.grad = gr.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([pr], 10.0)
+        opt.step()
+        g = gr.to(d)
+        _lib.check(L.psvae_clip_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, part.data_ptr(), 10.0, 1e-3,
+                                     0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step, norm.data_ptr(), st))
+        assert abs(float(norm) - float(want_norm)) <= 1e-5 * float(want_norm)
+        check_close(p, pr.detach(), f'params after step {step}', rtol=1e-6, atol_scale=1e-6)

@@ -1,0 +1,191 @@
+"""The fused HIP training step (PSVAEModel.forward / backward / FusedClipAdam)
+against the CPU oracle on the same seeded inputs, and against the golden
+fixtures that hold the reference's own outputs.  Floating point: rtol 1e-4."""
+import random
+
+import pytest
+import torch
+
+from oracle import collate_oracle as CO
+from oracle import psvae_oracle as O
+from tests.util import check_close, check_mostly_close, config_from_dims, load_golden
+
+pytestmark = pytest.mark.gpu
+MODEL_CASES = ['model_small_edge.pt', 'model_small_t3.pt', 'model_zinc_v300.pt', 'model_qm9_v500.pt']
+
+
+def build(d, vocab_size, seed=2021):
+    from ps_vae_amd import PSVAEModel, Tokenizer
+    tok = Tokenizer.synthetic(vocab_size)
+    model = PSVAEModel(config_from_dims(d, tok), tok)
+    sd = O.make_params(d, seed)
+    model.load_state_dict(sd)
+    return model.cuda(), tok, sd
+
+
+def collate_both(mols, tok, vocab_size, seed):
+    from ps_vae_amd.data import BPEMolDataset, to_device
+    random.seed(seed)
+    ref_batch = CO.collate([CO.to_matrix_form(m) for m in mols], vocab_size)
+    random.seed(seed)
+    batch = BPEMolDataset.process_step3([BPEMolDataset.process_step2(m, tok) for m in mols], tok)
+    return ref_batch, to_device(batch, 'cuda:0')
+
+
+def unpad(t, mask):
+    """[B*N, F] padded rows -> packed rows of real atoms."""
+    return t[~mask.flatten()]
+
+
+def compare_forward_backward(model, d, sd, ref_batch, batch, eps):
+    tr = O.Trainer(sd, d)
+    keep = {}
+    losses_ref = O.forward(tr.p, d, ref_batch, eps, keep)
+    total_ref = O.weighted_loss(losses_ref, 0)
+    total_ref.backward()
+    model.zero_grad()
+    pred, (rec, piece, edge, kl) = model(batch, eps=eps)
+    total = model.weighted_loss(pred, rec, kl)
+    got = dict(pred=pred, rec=rec, piece=piece, edge=edge, kl=kl)
+    for k, v in losses_ref.items():
+        assert abs(float(got[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, float(got[k]), float(v))
+    nb = batch['_native']
+    n, B, S, L = (nb.sizes[k] for k in ('n', 'B', 'S', 'L'))
+    H, te, td, T = d['hidden'], d['t_enc'], d['t_dec'], L - 1
+    mask = ref_batch['atom_mask']
+    enc = model.activation('enc_stack', n, (te + 1) * H)
+    dec = model.activation('dec_stack', n, (td + 1) * H)
+    for l in range(te + 1):
+        check_close(enc[:, l * H:(l + 1) * H], unpad(keep['enc_layers'][l], mask), f'encoder layer stack slice {l}')
+    for l in range(td + 1):
+        check_close(dec[:, l * H:(l + 1) * H], unpad(keep['dec_layers'][l], mask), f'decoder layer stack slice {l}')
+    check_close(model.activation('x0', n, d['d_atom'] + d['d_piece'] + d['d_pos']), unpad(keep['x0'].flatten(0, 1), mask), 'x0')
+    check_close(model.activation('pooled', B, te * H), keep['pooled'], 'pooled')
+    check_close(model.activation('cond', B, d['graph']), keep['cond'], 'cond')
+    check_close(model.activation('mulv', B, 2 * d['latent'])[:, :d['latent']], keep['z_mean'], 'z_mean')
+    check_close(model.activation('z', B, d['latent']), keep['z'], 'z')
+    check_close(model.activation('rnn_out', B * T, d['rnn']), keep['rnn_out'].flatten(0, 1), 'rnn_out')
+    V2 = d['num_piece']
+    check_close(model.activation('logits', B * T, V2, (V2 + 3) // 4 * 4), keep['logits'].flatten(0, 1), 'logits')
+    P = 2 * H + d['latent']
+    check_close(model.activation('pair_in', S, P), keep['pair_in'], 'pair_in')
+    check_close(model.activation('pair_logits', S, 4), keep['pair_logits'], 'pair_logits')
+    check_close(model.activation('pred', B, d['n_props'], (d['n_props'] + 3) // 4 * 4), keep['pred'], 'pred')
+    total.backward()
+    named = dict(model.named_parameters())
+    for name in tr.names:
+        g_ref = tr.p[name].grad
+        if g_ref is None:
+            assert named[name].grad is None, name
+        else:
+            check_close(named[name].grad, g_ref, f'grad {name}')
+    return tr
+
+
+@pytest.mark.parametrize('case', MODEL_CASES)
+def test_step_matches_oracle_and_reference_fixture(case):
+    g = load_golden(case)
+    d, V = g['dims'], g['vocab_size']
+    model, tok, sd = build(d, V, g['param_seed'])
+    ref_batch, batch = collate_both(g['mols'], tok, V, g['collate_seed'])
+    compare_forward_backward(model, d, sd, ref_batch, batch, g['eps'][0])
+    # three optimiser steps against the reference's recorded trajectory
+    model, tok, sd = build(d, V, g['param_seed'])
+    opt = model.configure_optimizers()
+    for s, ref in enumerate(g['steps']):
+        model.global_step = s
+        opt.zero_grad()
+        pred, (rec, piece, edge, kl) = model(batch, eps=g['eps'][s])
+        total = model.weighted_loss(pred, rec, kl)
+        total.backward()
+        opt.step()
+        got = dict(pred=pred, rec=rec, piece=piece, edge=edge, kl=kl, total=total)
+        for k, v in ref['losses'].items():
+            assert abs(float(got[k]) - v) <= 2e-4 * max(1.0, abs(v)), (s, k, float(got[k]), v)
+        assert abs(float(opt.grad_norm) - ref['grad_norm']) <= 1e-4 * ref['grad_norm']
+        named = dict(model.named_parameters())
+        for n_, want in ref['params_after'].items():
+            check_mostly_close(named[n_], want, f'step {s} param {n_}')
+    pred, (losses, accus) = model(batch, return_accu=True, eps=g['eps'][0])
+    assert list(accus) == pytest.approx(g['accus_after'], abs=1e-6)
+
+
+@pytest.mark.parametrize('shape,B,V', [('zinc', 128, 300), ('qm9', 32, 300), ('zinc', 48, 500)])
+def test_step_matches_oracle_at_benchmark_shapes(shape, B, V):
+    from ps_vae_amd import synth
+    d = O.default_dims(V)
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(100 + B, shape, V, B)
+    ref_batch, batch = collate_both(mols, tok, V, 7)
+    eps = torch.randn(B, d['latent'], generator=torch.Generator().manual_seed(5))
+    compare_forward_backward(model, d, sd, ref_batch, batch, eps)
+
+
+def test_encode_and_foreign_batch_dict():
+    from ps_vae_amd import synth
+    d, V, B = O.default_dims(300), 300, 16
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(31, 'zinc', V, B)
+    ref_batch, batch = collate_both(mols, tok, V, 3)
+    mean_ref, lvar_ref = O.get_z_mean(sd, d, ref_batch)
+    mean, lvar = model.encode(batch)
+    check_close(mean, mean_ref, 'z_mean')
+    check_close(lvar, lvar_ref, 'z_log_var')
+    # a batch dict without the packed entry (as foreign code would hand it over) gives the same result
+    foreign = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ref_batch.items()}
+    mean2, _ = model.encode(foreign)
+    assert torch.equal(mean2, mean)
+    z = model.get_z(batch, eps=torch.zeros(B, d['latent']))
+    assert torch.equal(z, mean)
+
+
+def test_gradient_accumulation_and_determinism():
+    from ps_vae_amd import synth
+    d, V, B = O.default_dims(300), 300, 32
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(77, 'zinc', V, B)
+    _, batch = collate_both(mols, tok, V, 11)
+    eps = torch.randn(B, d['latent'], generator=torch.Generator().manual_seed(1))
+
+    def grads():
+        model.zero_grad()
+        pred, (rec, _, _, kl) = model(batch, eps=eps)
+        model.weighted_loss(pred, rec, kl).backward()
+        return model.flat_buffers()[1].clone()
+    g1, g2 = grads(), grads()
+    assert torch.equal(g1, g2), 'two runs of the same step must be bitwise identical'
+    pred, (rec, _, _, kl) = model(batch, eps=eps)      # second backward without zero_grad accumulates
+    model.weighted_loss(pred, rec, kl).backward()
+    check_close(model.flat_buffers()[1], 2 * g1, 'accumulated gradient', rtol=1e-6)
+
+
+def test_module_level_encoder_matches_oracle():
+    """Encoder.embed_node / embed_graph and Predictor through the single-operator API."""
+    from ps_vae_amd import synth
+    d, V, B = O.default_dims(300), 300, 8
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(41, 'qm9', V, B)
+    ref_batch, batch = collate_both(mols, tok, V, 3)
+    p = {k: v.clone().requires_grad_(not k.endswith('eps')) for k, v in sd.items()}
+    x0 = torch.randn(B * ref_batch['x'].shape[1], 200, generator=torch.Generator().manual_seed(3))
+    layers = O.embed_node(x0, ref_batch['edge_index'], ref_batch['edge_attr'], p, 'encoder.', 4)
+    all_x_ref = torch.cat(layers[1:], -1)
+    N = ref_batch['x'].shape[1]
+    gid = torch.repeat_interleave(torch.arange(B), N)
+    _, cond_ref = O.embed_graph(all_x_ref, gid, ref_batch['atom_mask'].flatten(), p, 'encoder.')
+    cond_ref.sum().backward()
+    model.zero_grad()
+    for q in model.parameters():
+        q.grad = None
+    x_last, all_x = model.encoder.embed_node(x0.cuda(), batch['edge_index'], batch['edge_attr'])
+    cond = model.encoder.embed_graph(all_x, gid.cuda(), batch['atom_mask'].flatten())
+    check_close(all_x, all_x_ref, 'all_x')
+    check_close(cond, cond_ref, 'graph embedding')
+    cond.sum().backward()
+    for name in ('node_trans.weight', 'edge_trans.weight', 'edge_trans.bias', 'conv.nn.seq.0.weight', 'conv.nn.seq.2.bias', 'linear.weight'):
+        check_close(dict(model.encoder.named_parameters())[name].grad, p['encoder.' + name].grad, f'grad {name}')
+    z = torch.randn(B, 56, generator=torch.Generator().manual_seed(4))
+    q = torch.relu(torch.nn.functional.linear(z, sd['predictor.mlp.0.weight'], sd['predictor.mlp.0.bias']))
+    q = torch.relu(torch.nn.functional.linear(q, sd['predictor.mlp.2.weight'], sd['predictor.mlp.2.bias']))
+    want = torch.nn.functional.linear(q, sd['predictor.output.weight'], sd['predictor.output.bias'])
+    check_close(model.predictor(z.cuda()), want, 'predictor')

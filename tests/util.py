@@ -40,3 +40,38 @@ def check_close(got, want, what, rtol=RTOL, atol_scale=1e-5):
         i = int(err.argmax())
         raise AssertionError(f'{what}: max abs err {float(err.max()):.3e} at {i} '
                              f'(got {float(got.flatten()[i]):.6e}, want {float(ref.flatten()[i]):.6e}, scale {scale:.3e})')
+
+
+def config_from_dims(d, tok):
+    """Model config dict (the structure `src/train.py:130-132` assembles) from an oracle dims dict."""
+    return {
+        'lr': 1e-3, 'alpha': 0.1, 'beta': 0.0, 'max_beta': 0.01, 'step_beta': 0.002,
+        'kl_warmup': 0, 'kl_anneal_iter': 1000, 'selected_properties': [0, 2],
+        'predictor': {'dim_feature': d['latent'], 'dim_hidden': d['pred_hidden'], 'num_property': d['n_props']},
+        'encoder': {'dim_in': d['d_atom'] + d['d_piece'] + d['d_pos'], 'num_edge_type': d['num_bond'],
+                    'dim_hidden': d['hidden'], 'dim_out': d['graph'], 't': d['t_enc']},
+        'vae_piece_decoder': {'atom_embedding_dim': d['d_atom'], 'piece_embedding_dim': d['d_piece'],
+                              'max_pos': d['max_pos'], 'pos_embedding_dim': d['d_pos'],
+                              'piece_hidden_dim': d['rnn'], 'node_hidden_dim': d['hidden'],
+                              'num_edge_type': d['num_bond'], 'cond_dim': d['graph'],
+                              'latent_dim': d['latent'], 'tokenizer': tok, 't': d['t_dec']},
+    }
+
+
+def check_mostly_close(got, want, what, rtol=1e-4, atol=2e-5, max_bad_frac=2e-4):
+    """For post-optimiser parameters: Adam's first steps move a weight by ~lr * sign(g),
+    so an element whose gradient sits at rounding-noise level may differ by up to 2*lr.
+    Everything else must agree; the tolerated fraction of such elements is tiny."""
+    got = got.detach().float().cpu().flatten()
+    if isinstance(want, dict):
+        if 'full' in want:
+            ref = want['full'].flatten()
+        else:
+            got, ref = got[::want['stride']], want['sample']
+    else:
+        ref = want.detach().float().cpu().flatten()
+    bad = ~torch.isclose(got, ref, rtol=rtol, atol=atol)
+    frac = float(bad.float().mean()) if bad.numel() else 0.0
+    assert frac <= max_bad_frac, f'{what}: {int(bad.sum())}/{bad.numel()} elements differ (max {float((got - ref).abs().max()):.3e})'
+    if bad.any():
+        assert float((got - ref).abs().max()) <= 2.5e-3, f'{what}: outlier beyond 2*lr'
