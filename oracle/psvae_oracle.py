@@ -125,8 +125,9 @@ def gine_conv(x, src, dst, e, p, pre):
 
 def embed_node(x, edge_index, edge_attr_onehot, p, pre, t):
     """`Encoder.embed_node` (`src/modules/encoder.py:53-61`)."""
-    h = F.linear(x.float(), p[pre + 'node_trans.weight'], p[pre + 'node_trans.bias'])
-    e = F.linear(edge_attr_onehot.float(), p[pre + 'edge_trans.weight'], p[pre + 'edge_trans.bias'])
+    w = p[pre + 'node_trans.weight']
+    h = F.linear(x.to(w.dtype), w, p[pre + 'node_trans.bias'])
+    e = F.linear(edge_attr_onehot.to(w.dtype), p[pre + 'edge_trans.weight'], p[pre + 'edge_trans.bias'])
     src, dst = edge_index[0], edge_index[1]
     layers = [h]
     for _ in range(t):
@@ -138,7 +139,7 @@ def embed_node(x, edge_index, edge_attr_onehot, p, pre, t):
 def embed_graph(all_x, graph_ids, node_mask, p, pre):
     """`Encoder.embed_graph` (`src/modules/encoder.py:63-69`)."""
     n_graph = int(graph_ids[-1]) + 1
-    pooled = torch.zeros(n_graph, all_x.shape[-1])
+    pooled = torch.zeros(n_graph, all_x.shape[-1], dtype=all_x.dtype)
     keep = ~node_mask
     pooled.index_add_(0, graph_ids[keep], all_x[keep])
     return pooled, F.linear(pooled, p[pre + 'linear.weight'], p[pre + 'linear.bias'])
@@ -227,7 +228,7 @@ def forward(p, d, batch, eps, keep=None):
     q = torch.relu(F.linear(q, p['predictor.mlp.2.weight'], p['predictor.mlp.2.bias']))
     pred = F.linear(q, p['predictor.output.weight'], p['predictor.output.bias'])
     A['pred'] = pred
-    golden = batch['props'].reshape(B, -1)[:, batch.get('selected_properties', [0, 2])].float()
+    golden = batch['props'].reshape(B, -1)[:, batch.get('selected_properties', [0, 2])].to(pred.dtype)
     pred_loss = F.mse_loss(pred, golden)
     return {'pred': pred_loss, 'rec': piece_loss + edge_loss, 'piece': piece_loss,
             'edge': edge_loss, 'kl': kl}

@@ -190,7 +190,7 @@ class PSVAEModel(nn.Module):
         if self._grads_fresh:
             return self._grads_struct, True
         if self._gtmp is None:
-            self._gtmp = torch.empty_like(self._gflat)
+            self._gtmp = torch.zeros_like(self._gflat)   # padding slots stay zero
             self._gtmp_struct = self._struct_over(self._gtmp)
         return self._gtmp_struct, False
 

@@ -14,7 +14,7 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name), weights_only=False)
 
 
-def check_close(got, want, what, rtol=RTOL, atol_scale=1e-5):
+def check_close(got, want, what, rtol=RTOL, atol_scale=1e-5, bad_frac=0.0, outlier_scale=2e-3):
     """`want` is either a tensor or a compressed record from the fixture
     script ({'full': t} or {'sample','stride','l2','sum'})."""
     got = got.detach().float().cpu()
@@ -34,7 +34,11 @@ def check_close(got, want, what, rtol=RTOL, atol_scale=1e-5):
         got = got.reshape(ref.shape)
     scale = float(ref.abs().max()) if ref.numel() else 0.0
     atol = atol_scale * max(scale, 1e-6)
-    ok = torch.allclose(got, ref, rtol=rtol, atol=atol)
+    bad = ~torch.isclose(got, ref, rtol=rtol, atol=atol)
+    ok = not bool(bad.any())
+    if not ok and bad_frac > 0.0:
+        # tolerated outliers (see the caller's comment): few, and bounded relative to the tensor's scale
+        ok = int(bad.sum()) <= max(bad_frac * bad.numel(), 4) and float((got - ref).abs().max()) <= outlier_scale * max(scale, 1e-6)
     if not ok:
         err = (got - ref).abs()
         i = int(err.argmax())
