@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PS-VAE training step (encoder + decoder forward + backward,
+global-norm clip + Adam) on synthetic ZINC250K-shape graphs.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimiser step over one batch of 128 graphs per GPU (vocab 300,
+hidden 300: the configuration the metric is quoted on).  Batches are collated on
+the host beforehand and resident in HBM when the timed region starts; parameters
+are randomly initialised (no checkpoints exist offline).  With N > 1 every rank
+processes its own 128 graphs (weak scaling) and the flat gradient buffer is
+all-reduced over RCCL each step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config, synth  # noqa: E402
+from ps_vae_amd import _lib  # noqa: E402
+from ps_vae_amd.data import BPEMolDataset, to_device  # noqa: E402
+from ps_vae_amd.parallel import GradReducer  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+FLOP_CLASSES = ('gemm_forward', 'gemm_input_grad', 'gemm_weight_grad', 'gru_forward', 'gru_backward')
+
+
+def make_batches(tok, vocab, shape, batch_size, count, seed):
+    random.seed(seed)
+    out, t_collate = [], 0.0
+    for i in range(count):
+        mols = synth.make_molecules(seed * 1000 + i, shape, vocab, batch_size)
+        step2 = [BPEMolDataset.process_step2(m, tok) for m in mols]
+        t0 = time.perf_counter()
+        out.append(BPEMolDataset.process_step3(step2, tok))
+        t_collate += time.perf_counter() - t0
+    return out, t_collate / count
+
+
+def cpu_baseline(cpu_batch, vocab, budget_s=12.0, max_steps=8):
+    """The CPU oracle's training step (the reference's op sequence in plain PyTorch) on the host cores."""
+    from oracle import psvae_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    d = O.default_dims(vocab)
+    tr = O.Trainer(O.make_params(d), d)
+    B = cpu_batch['x'].shape[0]
+    eps = torch.randn(B, d['latent'])
+    tr.step(cpu_batch, eps)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < max_steps and (time.perf_counter() - t0 < budget_s or n == 0):
+        tr.step(cpu_batch, eps)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': B * n / dt, 'unit': 'molecules/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} training steps of the CPU oracle on one batch of {B} synthetic ZINC-shape graphs '
+                      f'({dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch-size', type=int, default=128, help='graphs per GPU')
+    ap.add_argument('--vocab', type=int, default=300)
+    ap.add_argument('--shape', default='zinc')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    tok = Tokenizer.synthetic(args.vocab)
+    torch.manual_seed(2021)
+    model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)
+    opt = model.configure_optimizers()
+    n_distinct = 8
+    cpu_batches, collate_s = make_batches(tok, args.vocab, args.shape, args.batch_size, n_distinct, seed=2021 + rank)
+    batches = [to_device(b, dev) for b in cpu_batches]
+    model.flat_buffers()
+    reducer = GradReducer(model.bucket_bounds)
+    local_denoms = [b['_native'].denoms.clone() for b in batches]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def step(i):
+        batch = batches[i % n_distinct]
+        nb = batch['_native']
+        if world > 1:
+            reducer.reduce_denoms(local_denoms[i % n_distinct], out=nb.denoms)
+        eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
+        opt.zero_grad()
+        pred, (rec, _piece, _edge, kl) = model(batch, eps=eps)
+        loss = model.weighted_loss(pred, rec, kl)
+        loss.backward()
+        if world > 1:
+            reducer.reduce_grads(model.flat_buffers()[1])
+        opt.step()
+        model.global_step += 1
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    # roofline pass: same steps with every launch bracketed by HIP events on its stream
+    L = _lib.lib()
+    L.psvae_profile_enable(1)
+    for i in range(args.profile_steps):
+        step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    classes = _lib.profile_collect()
+    L.psvae_profile_enable(0)
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch_size * args.steps / elapsed
+    table = {}
+    for name, (ms, work, cnt) in classes.items():
+        per_launch_us = ms / cnt * 1e3
+        rate = work / (ms * 1e-3) if ms > 0 else 0.0
+        if name in FLOP_CLASSES:
+            table[name] = {'us_per_step': ms / args.profile_steps * 1e3, 'launches_per_step': cnt / args.profile_steps,
+                           'avg_us': per_launch_us, 'TFLOPs': rate / 1e12}
+        else:
+            table[name] = {'us_per_step': ms / args.profile_steps * 1e3, 'launches_per_step': cnt / args.profile_steps,
+                           'avg_us': per_launch_us, 'GBs': rate / 1e9}
+    dom = max(classes, key=lambda k: classes[k][0])
+    dms, dwork, dcnt = classes[dom]
+    if dom in FLOP_CLASSES:
+        achieved, peak, unit, bound = dwork / (dms * 1e-3) / 1e12, MFMA_F32_PEAK_TF, 'TFLOP/s', 'mfma'
+    else:
+        achieved, peak, unit, bound = dwork / (dms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s', 'hbm'
+    roofline = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
+                'traffic': None, 'avg_launch_us': dms / dcnt * 1e3, 'launches_per_step': dcnt / args.profile_steps}
+    mp = [k for k in ('gine_aggregate_fwd', 'gine_aggregate_bwd') if k in classes]
+    mp_ms = sum(classes[k][0] for k in mp)
+    mp_bytes = sum(classes[k][1] for k in mp)
+    out = {
+        'metric': 'train molecules/sec (enc+dec fwd+bwd), ZINC-shape', 'value': value, 'unit': 'molecules/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'ZINC250K-shape training step, vocab {args.vocab}, hidden 300, batch {args.batch_size} per GPU '
+                               f'(fwd + bwd + clip + Adam{" + RCCL grad all-reduce" if world > 1 else ""})',
+                   'global_batch': world * args.batch_size, 'parallelism': f'dp{world}', 'params': int(model._n_trained),
+                   'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3},
+        'roofline': roofline,
+        'message_passing': {'kernels': mp, 'bound': 'hbm', 'achieved': (mp_bytes / (mp_ms * 1e-3) / 1e9) if mp_ms else None,
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': (mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mp_ms else None},
+        'kernel_classes': table,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cpu_batches[0], args.vocab)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

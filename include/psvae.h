@@ -156,6 +156,19 @@ int psvae_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_
                     float* partials, float max_norm, float lr, float beta1, float beta2, float adam_eps,
                     float bias1, float bias2, float* grad_norm_out, void* stream);
 
+/* ---- opt-in launch timer (benchmarking aid; no counterpart in the reference) ----
+ * While enabled, every kernel launch of the library is bracketed by hipEvents on
+ * its launch stream and tagged with a kernel class and its algorithmic work
+ * (FLOPs for the gemm_* classes and the GRU, bytes for the others).
+ * psvae_profile_collect waits for the recorded launches and ADDS duration (ms),
+ * work and launch count per class into three arrays of
+ * psvae_profile_num_classes() entries, then clears the log.  Off by default;
+ * not thread-safe. */
+int psvae_profile_enable(int on);
+int psvae_profile_num_classes(void);
+const char* psvae_profile_class_name(int kernel_class);
+int psvae_profile_collect(double* ms, double* work, int64_t* launches);
+
 /* ---- single operators (same kernels as the step; used by the module-level API
  * and the per-layer parity tests) -------------------------------------------- */
 /* nn.Linear (+ReLU) forward: y[M,N] = act(x[M,K] w[N,K]^T + b). src/modules/common_nn.py:15-23 */

@@ -87,6 +87,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m ps_vae_amd.build` '
                            '(there is no CPU fallback for the HIP kernels)')
+    # torch ships its own HIP runtime (libamdhip64); it must be the copy already mapped when this
+    # library is loaded, otherwise two runtimes coexist and torch's streams mean nothing to ours.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.psvae_strerror.restype = C.c_char_p
@@ -124,6 +127,11 @@ def lib():
     L.psvae_pack_bound.argtypes = [C.c_int, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.psvae_pack_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp,
                                    i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, P(i64), P(i32), P(i32)]
+    L.psvae_profile_enable.argtypes = [C.c_int]
+    L.psvae_profile_num_classes.restype = C.c_int
+    L.psvae_profile_class_name.restype = C.c_char_p
+    L.psvae_profile_class_name.argtypes = [C.c_int]
+    L.psvae_profile_collect.argtypes = [vp, vp, vp]
     if L.psvae_abi_version() != 1:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
@@ -137,7 +145,18 @@ EXPORTS = (
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_gine_edge_grad', 'psvae_segment_pool_forward',
     'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
-    'psvae_pack_bound', 'psvae_pack_batch')
+    'psvae_pack_bound', 'psvae_pack_batch', 'psvae_profile_enable', 'psvae_profile_num_classes',
+    'psvae_profile_class_name', 'psvae_profile_collect')
+
+
+def profile_collect():
+    """{class name: (milliseconds, work, launches)} since the last call; clears the log."""
+    import numpy as np
+    L = lib()
+    k = L.psvae_profile_num_classes()
+    ms, work, cnt = np.zeros(k), np.zeros(k), np.zeros(k, dtype=np.int64)
+    check(L.psvae_profile_collect(ms.ctypes.data, work.ctypes.data, cnt.ctypes.data), 'psvae_profile_collect')
+    return {L.psvae_profile_class_name(i).decode(): (float(ms[i]), float(work[i]), int(cnt[i])) for i in range(k) if cnt[i]}
 
 
 def check(rc, what='psvae call'):

@@ -59,7 +59,7 @@ extern "C" int psvae_gine_aggregate_forward(const float* x, int ldx, const int32
                                             float one_plus_eps, float* out, int ldo, int n, int H, void* stream) {
     if (!x || !rowptr || !edge_w || !edge_b || !out) return PSVAE_E_NULL;
     if (n < 0 || H < 4 || ldx < H || ldo < H) return PSVAE_E_SHAPE;
-    AggGroup g{x, out, rowptr, col, etype, edge_w, edge_b, one_plus_eps};
+    AggGroup g{x, out, rowptr, col, etype, edge_w, edge_b, one_plus_eps, 0};
     return gine_agg_fwd((hipStream_t)stream, &g, 1, ldx, ldo, n, H);
 }
 
@@ -69,7 +69,7 @@ extern "C" int psvae_gine_aggregate_backward(const float* da, int ldda, const fl
                                              const int32_t* node_graph, float* dx, int lddx, int n, int H, void* stream) {
     if (!dx || (da && (!x || !rowptr_t || !edge_w || !edge_b))) return PSVAE_E_NULL;
     if (n < 0 || H < 4 || lddx < H) return PSVAE_E_SHAPE;
-    AggBwdGroup g{da, x, dx, rowptr_t, col_t, etype_t, edge_w, edge_b, one_plus_eps, dpool};
+    AggBwdGroup g{da, x, dx, rowptr_t, col_t, etype_t, edge_w, edge_b, one_plus_eps, dpool, 0};
     return gine_agg_bwd((hipStream_t)stream, &g, 1, da ? ldda : H, da ? ldx : H, lddx, dpool ? ldp : H, node_graph, n, H);
 }
 

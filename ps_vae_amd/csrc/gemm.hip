@@ -7,13 +7,17 @@
 //                                   split over grid.z into slabs that a second
 //                                   kernel sums in a fixed order (bitwise reproducible)
 // Workgroup = 256 threads = 4 waves, 64x64 output tile, each wave one 32x32
-// accumulator; K-step 16, operands staged through LDS as [k][row] so that the
-// MFMA operand read (lane l: row l&31, k l>>5) is one conflict-free ds_read_b32.
+// accumulator; K-step 32.  Operands are staged through LDS as [k][row] so that
+// the MFMA operand read (lane l: row l&31, k l>>5) is one conflict-free
+// ds_read_b32.  The problems here are small (a few thousand rows), so a
+// workgroup's time is set by load latency, not bandwidth: tiles are fetched two
+// K-steps ahead into two named register stages (global -> VGPR -> LDS), which
+// keeps ~2 x 16 MFMAs of work between a load's issue and its first use.
 #include "psvae_internal.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = 64 + 4;
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 64 + 4;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct GemmP {
@@ -29,61 +33,91 @@ struct GemmP {
     long long slab_stride;
 };
 
-// Load this thread's 4 staged elements of one operand tile.
-//  !T: X[o*ld + r]: thread -> row o = o0 + tid/4, r = r0 + 4*(tid%4) .. +3
-//   T: X[r*ld + o]: thread -> r = r0 + tid/16, o = o0 + 4*(tid%16) .. +3
-template <bool T>
-__device__ __forceinline__ float4 load_stage(const float* __restrict__ X, int ld, int o0, int o_lim, int r0, int r_lim,
-                                             int tid, int vec, int ones_col) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!T) {
-        const int o = o0 + (tid >> 2), r = r0 + ((tid & 3) << 2);
-        if (o < o_lim) {
-            const float* p = X + (long long)o * ld + r;
-            if (vec && r + 3 < r_lim) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (r < r_lim) v.x = p[0];
-                if (r + 1 < r_lim) v.y = p[1];
-                if (r + 2 < r_lim) v.z = p[2];
-                if (r + 3 < r_lim) v.w = p[3];
-            }
-        }
+// This thread's 8 elements of one 64 x 32 operand tile, as loaded, plus per-element flags.
+// The flags are applied only when the stage is written to LDS: touching a loaded value
+// earlier would make the compiler wait for the load right after issuing it.
+struct Stage { float4 v0, v1; unsigned flags; };   // bits 0-3 / 4-7: element valid; bits 8-11 / 12-15: element is the ones column
+
+// One float4 of an operand tile, without branches (a branch around a load makes the
+// compiler drain the whole load queue at the join, which would serialise the prefetch):
+// the address is clamped into the matrix, the load is unconditional, and elements that
+// lie outside the tile's valid range are flagged to be zeroed later.
+//  !T: X[o*ld + r]: slot q -> row o = o0 + q/8, r = r0 + 4*(q%8) .. +3   (vector along r)
+//   T: X[r*ld + o]: slot q -> r = r0 + q/16,   o = o0 + 4*(q%16) .. +3   (vector along o)
+// VEC: base 16-byte aligned and ld % 4 == 0, so a float4 that starts inside a row stays
+// inside that row's ld floats even when it overhangs the valid width.
+template <bool T, bool VEC>
+__device__ __forceinline__ float4 load_quad(const float* __restrict__ X, int ld, int o0, int o_lim, int r0, int r_lim,
+                                            int q, int ones_col, unsigned& flags) {
+    const int o = T ? o0 + ((q & 15) << 2) : o0 + (q >> 3);
+    const int r = T ? r0 + (q >> 4) : r0 + ((q & 7) << 2);
+    const int first = T ? o : r;                                              // index along the vector
+    const int lim = T ? (ones_col >= 0 ? ones_col : o_lim) : r_lim;           // valid extent along the vector
+    const bool line_ok = T ? (r < r_lim) : (o < o_lim);
+    const bool any = line_ok && first < lim;
+    const float* p = X + (any ? (long long)(T ? r : o) * ld + first : 0);
+    const bool ok1 = any && first + 1 < lim, ok2 = any && first + 2 < lim, ok3 = any && first + 3 < lim;
+    flags = (any ? 1u : 0u) | (ok1 ? 2u : 0u) | (ok2 ? 4u : 0u) | (ok3 ? 8u : 0u);
+    if (T && ones_col >= 0 && line_ok) {
+        const int d = ones_col - o;
+        if (d >= 0 && d < 4) flags |= 0x100u << d;
+    }
+    float4 v;
+    if (VEC) {
+        v = *reinterpret_cast<const float4*>(p);
     } else {
-        const int r = r0 + (tid >> 4), o = o0 + ((tid & 15) << 2);
-        if (r < r_lim) {
-            const int real_lim = ones_col >= 0 ? ones_col : o_lim;  // columns that exist in memory
-            const float* p = X + (long long)r * ld + o;
-            if (vec && o + 3 < real_lim) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (o < real_lim) v.x = p[0];
-                if (o + 1 < real_lim) v.y = p[1];
-                if (o + 2 < real_lim) v.z = p[2];
-                if (o + 3 < real_lim) v.w = p[3];
-            }
-            if (ones_col >= 0) {
-                if (o == ones_col) v.x = 1.f;
-                if (o + 1 == ones_col) v.y = 1.f;
-                if (o + 2 == ones_col) v.z = 1.f;
-                if (o + 3 == ones_col) v.w = 1.f;
-            }
-        }
+        // unaligned operand: four scalar loads, each clamped to the first element when out of range
+        v.x = p[0]; v.y = p[ok1 ? 1 : 0]; v.z = p[ok2 ? 2 : 0]; v.w = p[ok3 ? 3 : 0];
     }
     return v;
 }
 
-template <bool T>
-__device__ __forceinline__ void store_stage(float (*s)[LDS_LD], float4 v, int tid) {
-    if (!T) {
-        const int row = tid >> 2, k = (tid & 3) << 2;
-        s[k][row] = v.x; s[k + 1][row] = v.y; s[k + 2][row] = v.z; s[k + 3][row] = v.w;
-    } else {
-        *reinterpret_cast<float4*>(&s[tid >> 4][(tid & 15) << 2]) = v;
-    }
+template <bool T, bool VEC>
+__device__ __forceinline__ Stage load_stage(const float* __restrict__ X, int ld, int o0, int o_lim, int r0, int r_lim,
+                                            int tid, int ones_col) {
+    Stage s;
+    unsigned f0, f1;
+    s.v0 = load_quad<T, VEC>(X, ld, o0, o_lim, r0, r_lim, tid, ones_col, f0);
+    s.v1 = load_quad<T, VEC>(X, ld, o0, o_lim, r0, r_lim, tid + 256, ones_col, f1);
+    s.flags = (f0 & 0xFu) | ((f1 & 0xFu) << 4) | (f0 & 0xF00u) | ((f1 & 0xF00u) << 4);
+    return s;
 }
 
-template <bool AT, bool BT>
+__device__ __forceinline__ float4 apply_flags(float4 v, unsigned valid, unsigned ones) {
+    v.x = (valid & 1u) ? v.x : 0.f; v.y = (valid & 2u) ? v.y : 0.f;
+    v.z = (valid & 4u) ? v.z : 0.f; v.w = (valid & 8u) ? v.w : 0.f;
+    v.x = (ones & 1u) ? 1.f : v.x; v.y = (ones & 2u) ? 1.f : v.y;
+    v.z = (ones & 4u) ? 1.f : v.z; v.w = (ones & 8u) ? 1.f : v.w;
+    return v;
+}
+
+template <bool T>
+__device__ __forceinline__ void store_quad(float (*s)[LDS_LD], float4 v, int q) {
+    if (!T) {
+        const int row = q >> 3, k = (q & 7) << 2;
+        s[k][row] = v.x; s[k + 1][row] = v.y; s[k + 2][row] = v.z; s[k + 3][row] = v.w;
+    } else {
+        *reinterpret_cast<float4*>(&s[q >> 4][(q & 15) << 2]) = v;
+    }
+}
+template <bool T>
+__device__ __forceinline__ void store_stage(float (*s)[LDS_LD], const Stage& st, int tid) {
+    store_quad<T>(s, apply_flags(st.v0, st.flags & 0xFu, (st.flags >> 8) & 0xFu), tid);
+    store_quad<T>(s, apply_flags(st.v1, (st.flags >> 4) & 0xFu, (st.flags >> 12) & 0xFu), tid + 256);
+}
+
+__device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LDS_LD], const float (*sb)[LDS_LD], int arow, int brow,
+                                              int kh, floatx16 acc) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        const float a = sa[kk * 2 + kh][arow];
+        const float b = sb[kk * 2 + kh][brow];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <bool AT, bool BT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) float sA[2][BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[2][BK][LDS_LD];
@@ -102,28 +136,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     if (nk > 0) {
-        float4 ra = load_stage<AT>(A, p.lda, m0, p.M, rbeg, rend, tid, p.a_vec, -1);
-        float4 rb = load_stage<BT>(B, p.ldb, n0, p.N, rbeg, rend, tid, p.b_vec, p.ones_col);
-        store_stage<AT>(sA[0], ra, tid);
-        store_stage<BT>(sB[0], rb, tid);
-        __syncthreads();
         const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = lane >> 5;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) {
-                const int r0 = rbeg + (kt + 1) * BK;
-                ra = load_stage<AT>(A, p.lda, m0, p.M, r0, rend, tid, p.a_vec, -1);
-                rb = load_stage<BT>(B, p.ldb, n0, p.N, r0, rend, tid, p.b_vec, p.ones_col);
+        // register stages: E holds the next odd tile, O... named so that every access is static
+        Stage a0 = load_stage<AT, VEC>(A, p.lda, m0, p.M, rbeg, rend, tid, -1);
+        Stage b0 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, rbeg, rend, tid, p.ones_col);
+        Stage a1 = load_stage<AT, VEC>(A, p.lda, m0, p.M, rbeg + BK, rend, tid, -1);   // empty (zeros) when nk == 1
+        Stage b1 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, rbeg + BK, rend, tid, p.ones_col);
+        store_stage<AT>(sA[0], a0, tid);
+        store_stage<BT>(sB[0], b0, tid);
+        __syncthreads();
+        // invariant at the top of iteration kt: LDS buffer kt&1 holds tile kt, stage (kt+1)&1 holds tile kt+1
+        for (int kt = 0; kt < nk; kt += 2) {
+            // ---- even half: compute tile kt from buffer 0; stage 0 is free -> fetch tile kt+2 into it
+            if (kt + 2 < nk) {
+                const int r0 = rbeg + (kt + 2) * BK;
+                a0 = load_stage<AT, VEC>(A, p.lda, m0, p.M, r0, rend, tid, -1);
+                b0 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, r0, rend, tid, p.ones_col);
             }
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                const float a = sA[buf][kk * 2 + kh][arow];
-                const float b = sB[buf][kk * 2 + kh][brow];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
+            acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
             if (kt + 1 < nk) {
-                store_stage<AT>(sA[buf ^ 1], ra, tid);
-                store_stage<BT>(sB[buf ^ 1], rb, tid);
+                store_stage<AT>(sA[1], a1, tid);
+                store_stage<BT>(sB[1], b1, tid);
+            }
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // ---- odd half: compute tile kt+1 from buffer 1; stage 1 is free -> fetch tile kt+3
+            if (kt + 3 < nk) {
+                const int r0 = rbeg + (kt + 3) * BK;
+                a1 = load_stage<AT, VEC>(A, p.lda, m0, p.M, r0, rend, tid, -1);
+                b1 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, r0, rend, tid, p.ones_col);
+            }
+            acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
+            if (kt + 2 < nk) {
+                store_stage<AT>(sA[0], a0, tid);
+                store_stage<BT>(sB[0], b0, tid);
             }
             __syncthreads();
         }
@@ -176,7 +222,13 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e / p.N), j = (int)(e - (long long)i * p.N);
         float v = 0.f;
-        for (int z = 0; z < p.nz; ++z) v += s[(long long)z * p.slab_stride + e];
+        int z = 0;
+        for (; z + 4 <= p.nz; z += 4) {   // 4 independent loads in flight, summed in slab order
+            const float v0 = s[(long long)z * p.slab_stride + e], v1 = s[(long long)(z + 1) * p.slab_stride + e];
+            const float v2 = s[(long long)(z + 2) * p.slab_stride + e], v3 = s[(long long)(z + 3) * p.slab_stride + e];
+            v = (((v + v0) + v1) + v2) + v3;
+        }
+        for (; z < p.nz; ++z) v += s[(long long)z * p.slab_stride + e];
         if (p.bias) v += p.bias[seg * p.seg_bias + j];
         if (p.relu) v = fmaxf(v, 0.f);
         if (j == p.ones_col) {
@@ -189,13 +241,15 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
     }
 }
 
+// Reduction split: aim for ~4 workgroups per CU (occupancy hides the load latency of
+// these short K loops) while keeping at least 4 K-steps per workgroup.
 struct Plan { int splits, rchunk; };
 Plan plan_splits(int M, int N, int R, int nseg) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nseg;
     Plan pl{1, (int)round_up(R > 0 ? R : 1, BK)};
-    if (tiles >= 160 || R <= 128) return pl;
-    int want = (int)((256 + tiles - 1) / tiles);
-    int maxs = (R + 63) / 64;
+    if (tiles >= 200 || R <= 4 * BK) return pl;
+    int want = (int)((1024 + tiles - 1) / tiles);
+    int maxs = R / (4 * BK);
     if (want > maxs) want = maxs;
     if (want <= 1) return pl;
     pl.rchunk = (int)round_up((R + want - 1) / want, BK);
@@ -222,9 +276,14 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
     if (slab) {
         const size_t need = (size_t)(nz_total * (long long)d.M * d.N);
         if (!d.scratch || d.scratch_floats < need) {
-            if (d.sum_segments && d.nseg > 1) return PSVAE_E_WORKSPACE;
+            if (d.sum_segments && d.nseg > 1) {
+                // fall back to one slab per segment if that fits, else give up
+                if (!d.scratch || d.scratch_floats < (size_t)d.nseg * d.M * d.N) return PSVAE_E_WORKSPACE;
+            } else {
+                slab = false;
+            }
             pl.splits = 1; pl.rchunk = (int)round_up(d.R > 0 ? d.R : 1, BK);
-            nz_total = d.nseg; slab = false;
+            nz_total = d.nseg;
         }
     }
     GemmP p;
@@ -241,10 +300,21 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
     p.slab_stride = (long long)d.M * d.N;
     dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (unsigned)nz_total);
     if (grid.y > 65535 || grid.z > 65535) return PSVAE_E_SHAPE;
-    if (!d.a_t && !d.b_t) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
-    else if (!d.a_t && d.b_t) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
-    else if (d.a_t && d.b_t) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
+    const double flops = 2.0 * d.M * d.N * d.R * d.nseg;
+    {
+        ProfScope prof(s, d.a_t ? KC_GEMM_DW : (d.b_t ? KC_GEMM_DX : KC_GEMM_FWD), flops);
+        const bool vec = p.a_vec && p.b_vec;
+#define PSVAE_GEMM_LAUNCH(AT_, BT_)                                                                          \
+        do {                                                                                                  \
+            if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, true>), grid, dim3(256), 0, s, p);         \
+            else hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, false>), grid, dim3(256), 0, s, p);            \
+        } while (0)
+        if (!d.a_t && !d.b_t) PSVAE_GEMM_LAUNCH(false, false);
+        else if (!d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(false, true);
+        else if (d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(true, true);
+        else PSVAE_GEMM_LAUNCH(true, false);
+#undef PSVAE_GEMM_LAUNCH
+    }
     PSVAE_LAUNCH_CHECK();
     if (slab) {
         ReduceP r;
@@ -259,6 +329,7 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         dim3 rgrid(blocks, d.sum_segments ? 1 : d.nseg);
+        ProfScope prof(s, KC_GEMM_REDUCE, 4.0 * total * (nz_total + 1));
         hipLaunchKernelGGL(gemm_reduce_kernel, rgrid, dim3(256), 0, s, r);
         PSVAE_LAUNCH_CHECK();
     }

@@ -44,13 +44,23 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     const float4 xi = ld4(g.x + (long long)i * a.ldx + c);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int e1 = g.rowptr[i + 1];
-    for (int e = g.rowptr[i]; e < e1; ++e) {
-        const float4 xj = ld4(g.x + (long long)g.col[e] * a.ldx + c);
-        const float4 ee = pick(et, g.etype[e]);
-        acc.x += fmaxf(xj.x + ee.x, 0.f);
-        acc.y += fmaxf(xj.y + ee.y, 0.f);
-        acc.z += fmaxf(xj.z + ee.z, 0.f);
-        acc.w += fmaxf(xj.w + ee.w, 0.f);
+    // neighbours in groups of 4: all index loads, then all row loads, are issued together
+    // (one latency round trip per group instead of per edge); the sum keeps edge order.
+    for (int e = g.rowptr[i]; e < e1; e += 4) {
+        const int m = e1 - e;
+        const int j0 = g.col[e], j1 = m > 1 ? g.col[e + 1] : j0, j2 = m > 2 ? g.col[e + 2] : j0, j3 = m > 3 ? g.col[e + 3] : j0;
+        const int t0 = g.etype[e], t1 = m > 1 ? g.etype[e + 1] : 0, t2 = m > 2 ? g.etype[e + 2] : 0, t3 = m > 3 ? g.etype[e + 3] : 0;
+        const float4 x0 = ld4(g.x + (long long)j0 * a.ldx + c), x1 = ld4(g.x + (long long)j1 * a.ldx + c);
+        const float4 x2 = ld4(g.x + (long long)j2 * a.ldx + c), x3 = ld4(g.x + (long long)j3 * a.ldx + c);
+        const float4 e0 = pick(et, t0), ee1 = pick(et, t1), ee2 = pick(et, t2), ee3 = pick(et, t3);
+        acc.x += fmaxf(x0.x + e0.x, 0.f); acc.y += fmaxf(x0.y + e0.y, 0.f);
+        acc.z += fmaxf(x0.z + e0.z, 0.f); acc.w += fmaxf(x0.w + e0.w, 0.f);
+        if (m > 1) { acc.x += fmaxf(x1.x + ee1.x, 0.f); acc.y += fmaxf(x1.y + ee1.y, 0.f);
+                     acc.z += fmaxf(x1.z + ee1.z, 0.f); acc.w += fmaxf(x1.w + ee1.w, 0.f); }
+        if (m > 2) { acc.x += fmaxf(x2.x + ee2.x, 0.f); acc.y += fmaxf(x2.y + ee2.y, 0.f);
+                     acc.z += fmaxf(x2.z + ee2.z, 0.f); acc.w += fmaxf(x2.w + ee2.w, 0.f); }
+        if (m > 3) { acc.x += fmaxf(x3.x + ee3.x, 0.f); acc.y += fmaxf(x3.y + ee3.y, 0.f);
+                     acc.z += fmaxf(x3.z + ee3.z, 0.f); acc.w += fmaxf(x3.w + ee3.w, 0.f); }
     }
     st4(g.out + (long long)i * a.ldo + c,
         make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
@@ -68,13 +78,21 @@ __global__ __launch_bounds__(256) void gine_agg_bwd_kernel(const AggBwdArgs a) {
         const EdgeTab et = load_edge_tab(g.edge_w, g.edge_b, c);
         const float4 xj = ld4(g.x + (long long)j * a.ldx + c);
         const int e1 = g.rowptr_t[j + 1];
-        for (int e = g.rowptr_t[j]; e < e1; ++e) {
-            const float4 d = ld4(g.da + (long long)g.col_t[e] * a.ldda + c);
-            const float4 ee = pick(et, g.etype_t[e]);
-            acc.x += (xj.x + ee.x > 0.f) ? d.x : 0.f;
-            acc.y += (xj.y + ee.y > 0.f) ? d.y : 0.f;
-            acc.z += (xj.z + ee.z > 0.f) ? d.z : 0.f;
-            acc.w += (xj.w + ee.w > 0.f) ? d.w : 0.f;
+        for (int e = g.rowptr_t[j]; e < e1; e += 4) {   // groups of 4, as in the forward kernel
+            const int m = e1 - e;
+            const int i0 = g.col_t[e], i1 = m > 1 ? g.col_t[e + 1] : i0, i2 = m > 2 ? g.col_t[e + 2] : i0, i3 = m > 3 ? g.col_t[e + 3] : i0;
+            const int t0 = g.etype_t[e], t1 = m > 1 ? g.etype_t[e + 1] : 0, t2 = m > 2 ? g.etype_t[e + 2] : 0, t3 = m > 3 ? g.etype_t[e + 3] : 0;
+            const float4 d0 = ld4(g.da + (long long)i0 * a.ldda + c), d1 = ld4(g.da + (long long)i1 * a.ldda + c);
+            const float4 d2 = ld4(g.da + (long long)i2 * a.ldda + c), d3 = ld4(g.da + (long long)i3 * a.ldda + c);
+            const float4 e0 = pick(et, t0), ee1 = pick(et, t1), ee2 = pick(et, t2), ee3 = pick(et, t3);
+            acc.x += (xj.x + e0.x > 0.f) ? d0.x : 0.f; acc.y += (xj.y + e0.y > 0.f) ? d0.y : 0.f;
+            acc.z += (xj.z + e0.z > 0.f) ? d0.z : 0.f; acc.w += (xj.w + e0.w > 0.f) ? d0.w : 0.f;
+            if (m > 1) { acc.x += (xj.x + ee1.x > 0.f) ? d1.x : 0.f; acc.y += (xj.y + ee1.y > 0.f) ? d1.y : 0.f;
+                         acc.z += (xj.z + ee1.z > 0.f) ? d1.z : 0.f; acc.w += (xj.w + ee1.w > 0.f) ? d1.w : 0.f; }
+            if (m > 2) { acc.x += (xj.x + ee2.x > 0.f) ? d2.x : 0.f; acc.y += (xj.y + ee2.y > 0.f) ? d2.y : 0.f;
+                         acc.z += (xj.z + ee2.z > 0.f) ? d2.z : 0.f; acc.w += (xj.w + ee2.w > 0.f) ? d2.w : 0.f; }
+            if (m > 3) { acc.x += (xj.x + ee3.x > 0.f) ? d3.x : 0.f; acc.y += (xj.y + ee3.y > 0.f) ? d3.y : 0.f;
+                         acc.z += (xj.z + ee3.z > 0.f) ? d3.z : 0.f; acc.w += (xj.w + ee3.w > 0.f) ? d3.w : 0.f; }
         }
         const float4 dj = ld4(g.da + (long long)j * a.ldda + c);
         acc = make_float4(acc.x + g.ope * dj.x, acc.y + g.ope * dj.y, acc.z + g.ope * dj.z, acc.w + g.ope * dj.w);
@@ -83,58 +101,90 @@ __global__ __launch_bounds__(256) void gine_agg_bwd_kernel(const AggBwdArgs a) {
     st4(g.dx + (long long)j * a.lddx + c, acc);
 }
 
-// Edge-table gradient, stage 1: block (chunk, layer, group) sums, for its node
-// range, da[dst] * (x[src] + e(type) > 0) per bond type into partial[..][4][H].
+// Edge-table gradient, stage 1.  Block (chunk, layer, group) covers a range of target
+// nodes; threadIdx.x = channel-chunk lane, threadIdx.y = quarter of the node range.  Each
+// thread sums da[dst] * (x[src] + e(type) > 0) per bond type over its nodes, the four
+// quarters are combined in order through LDS and written to partial[layer][chunk][4][H].
 struct EtabArgs { EtabGroup g[2]; int t, ldda, ldx, n, H4, chunks; };
 
-__global__ __launch_bounds__(128) void gine_etab_partial_kernel(const EtabArgs a) {
+__global__ __launch_bounds__(256) void gine_etab_partial_kernel(const EtabArgs a) {
+    __shared__ float4 part[4][4][64];
     const EtabGroup& g = a.g[blockIdx.z];
-    const int chunk = blockIdx.x, layer = blockIdx.y;
-    const int per = (a.n + a.chunks - 1) / a.chunks;
-    const int i0 = chunk * per, i1 = min(a.n, i0 + per);
+    const int chunk = blockIdx.x, layer = blockIdx.y, tx = threadIdx.x, ty = threadIdx.y;
+    const int per = (a.n + a.chunks - 1) / a.chunks, q = (per + 3) / 4;
+    const int cend = min(a.n, (chunk + 1) * per);
+    const int i0 = min(cend, chunk * per + ty * q), i1 = min(cend, i0 + q);
     const float* da = g.da + (long long)layer * g.da_layer;
     const float* x = g.x + (long long)layer * g.x_layer;
-    float* out = g.partial + ((long long)layer * a.chunks + chunk) * 4 * (a.H4 * 4);
-    for (int c4 = threadIdx.x; c4 < a.H4; c4 += blockDim.x) {
-        const int c = c4 * 4;
-        const EdgeTab et = load_edge_tab(g.edge_w, g.edge_b, c);
+    const int H = a.H4 * 4;
+    float* out = g.partial + ((long long)layer * a.chunks + chunk) * 4 * H;
+    for (int c40 = 0; c40 < a.H4; c40 += 64) {
+        const int c4 = c40 + tx, c = c4 * 4;
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-        for (int i = i0; i < i1; ++i) {
-            const int e1 = g.rowptr[i + 1];
-            int e = g.rowptr[i];
-            if (e == e1) continue;
-            const float4 d = ld4(da + (long long)i * a.ldda + c);
-            for (; e < e1; ++e) {
-                const int ty = g.etype[e];
-                const float4 xs = ld4(x + (long long)g.col[e] * a.ldx + c);
-                const float4 ee = pick(et, ty);
-                const float4 v = make_float4(xs.x + ee.x > 0.f ? d.x : 0.f, xs.y + ee.y > 0.f ? d.y : 0.f,
-                                             xs.z + ee.z > 0.f ? d.z : 0.f, xs.w + ee.w > 0.f ? d.w : 0.f);
-                if (ty == 1) s1 = add4(s1, v);
-                else if (ty == 2) s2 = add4(s2, v);
-                else if (ty == 3) s3 = add4(s3, v);
-                else s0 = add4(s0, v);
+        if (c4 < a.H4) {
+            const EdgeTab et = load_edge_tab(g.edge_w, g.edge_b, c);
+            for (int i = i0; i < i1; ++i) {
+                const int e1 = g.rowptr[i + 1];
+                int e = g.rowptr[i];
+                if (e == e1) continue;
+                const float4 d = ld4(da + (long long)i * a.ldda + c);
+                for (; e < e1; ++e) {
+                    const int tp = g.etype[e];
+                    const float4 xs = ld4(x + (long long)g.col[e] * a.ldx + c);
+                    const float4 ee = pick(et, tp);
+                    const float4 v = make_float4(xs.x + ee.x > 0.f ? d.x : 0.f, xs.y + ee.y > 0.f ? d.y : 0.f,
+                                                 xs.z + ee.z > 0.f ? d.z : 0.f, xs.w + ee.w > 0.f ? d.w : 0.f);
+                    if (tp == 1) s1 = add4(s1, v);
+                    else if (tp == 2) s2 = add4(s2, v);
+                    else if (tp == 3) s3 = add4(s3, v);
+                    else s0 = add4(s0, v);
+                }
             }
         }
-        const int H = a.H4 * 4;
-        st4(out + c, s0); st4(out + H + c, s1); st4(out + 2 * H + c, s2); st4(out + 3 * H + c, s3);
+        part[ty][0][tx] = s0; part[ty][1][tx] = s1; part[ty][2][tx] = s2; part[ty][3][tx] = s3;
+        __syncthreads();
+        if (c4 < a.H4) {   // thread (tx, ty) finalises bond type ty: quarters added in order
+            const float4 v = add4(add4(add4(part[0][ty][tx], part[1][ty][tx]), part[2][ty][tx]), part[3][ty][tx]);
+            st4(out + ty * H + c, v);
+        }
+        __syncthreads();
     }
 }
-// stage 2: d_edge_w[c][ty] = sum of partials in (layer, chunk) order; d_edge_b[c] = sum over ty.
-__global__ __launch_bounds__(256) void gine_etab_final_kernel(const EtabArgs a) {
+// stage 2: d_edge_w[c][type] = sum of the partials in (layer, chunk) order, split into 8 ordered
+// slices per block and combined through LDS; d_edge_b[c] = sum over types.
+__global__ __launch_bounds__(512) void gine_etab_final_kernel(const EtabArgs a) {
+    __shared__ float4 part[8][4][64];
     const EtabGroup& g = a.g[blockIdx.y];
-    const int H = a.H4 * 4;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H) return;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    const int np = a.t * a.chunks;
-    for (int p = 0; p < np; ++p) {
-        const float* src = g.partial + (long long)p * 4 * H;
-#pragma unroll
-        for (int ty = 0; ty < 4; ++ty) s[ty] += src[ty * H + c];
+    const int H = a.H4 * 4, tx = threadIdx.x, ty = threadIdx.y;
+    const int c4 = blockIdx.x * 64 + tx, c = c4 * 4;
+    const int np = a.t * a.chunks, per = (np + 7) / 8;
+    const int p0 = min(np, ty * per), p1 = min(np, p0 + per);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (c4 < a.H4) {
+        for (int p = p0; p < p1; ++p) {
+            const float* src = g.partial + (long long)p * 4 * H + c;
+            s0 = add4(s0, ld4(src)); s1 = add4(s1, ld4(src + H)); s2 = add4(s2, ld4(src + 2 * H)); s3 = add4(s3, ld4(src + 3 * H));
+        }
     }
-    st4(g.d_edge_w + (long long)c * 4, make_float4(s[0], s[1], s[2], s[3]));
-    g.d_edge_b[c] = ((s[0] + s[1]) + s[2]) + s[3];
+    part[ty][0][tx] = s0; part[ty][1][tx] = s1; part[ty][2][tx] = s2; part[ty][3][tx] = s3;
+    __syncthreads();
+    if (ty == 0 && c4 < a.H4) {
+        float4 w[4];
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            float4 v = part[0][tp][tx];
+#pragma unroll
+            for (int y = 1; y < 8; ++y) v = add4(v, part[y][tp][tx]);
+            w[tp] = v;
+        }
+        // d_edge_w is [H][4]: channel c+k holds (type0..3)
+        st4(g.d_edge_w + (long long)c * 4, make_float4(w[0].x, w[1].x, w[2].x, w[3].x));
+        st4(g.d_edge_w + (long long)(c + 1) * 4, make_float4(w[0].y, w[1].y, w[2].y, w[3].y));
+        st4(g.d_edge_w + (long long)(c + 2) * 4, make_float4(w[0].z, w[1].z, w[2].z, w[3].z));
+        st4(g.d_edge_w + (long long)(c + 3) * 4, make_float4(w[0].w, w[1].w, w[2].w, w[3].w));
+        st4(g.d_edge_b + c, make_float4(((w[0].x + w[1].x) + w[2].x) + w[3].x, ((w[0].y + w[1].y) + w[2].y) + w[3].y,
+                                        ((w[0].z + w[1].z) + w[2].z) + w[3].z, ((w[0].w + w[1].w) + w[2].w) + w[3].w));
+    }
 }
 
 __global__ __launch_bounds__(256) void embed3_gather_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ p,
@@ -165,43 +215,71 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const int32_t* __restr
     }
 }
 
-// Embedding-table gradient: block = one table row; threadIdx.x = column lane,
-// threadIdx.y = slice of the row's contribution list.  Slices are combined in
-// slice order through LDS, so the sum order is fixed.
-constexpr int TG_X = 64, TG_Y = 8;
-__global__ __launch_bounds__(TG_X * TG_Y) void table_grad_kernel(float* __restrict__ dtable, int D,
-                                                                  const int32_t* __restrict__ ptr1, const int32_t* __restrict__ idx1,
-                                                                  const float* __restrict__ src1, int ld1, int off1,
-                                                                  const int32_t* __restrict__ ptr2, const int32_t* __restrict__ idx2,
-                                                                  const float* __restrict__ src2, int ld2, int off2) {
-    __shared__ float part[TG_Y][TG_X];
-    const int row = blockIdx.x, tx = threadIdx.x, ty = threadIdx.y;
-    for (int c0 = 0; c0 < D; c0 += TG_X) {
+// Embedding-table gradients for up to 3 tables in one launch.  Every table row owns up to
+// two contribution lists (index lists built on the host).  Stage 1: block (row, segment)
+// sums one of TG_SEG ordered segments of a list (threadIdx.y = quarter of the segment,
+// combined in order through LDS) into partial[row][segment][:].  Stage 2 adds a row's
+// non-empty segments in order.  No atomics: the sum order is fixed by the lists.
+constexpr int TG_SEG = 16;
+struct TableArgs { TableGradDesc t[3]; int row0[4]; int nt, dmax; float* partial; };
+
+__device__ __forceinline__ int tg_find(const TableArgs& a, int grow) {
+    int k = 0;
+    while (k + 1 < a.nt && grow >= a.row0[k + 1]) ++k;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void table_grad_partial_kernel(const TableArgs a) {
+    __shared__ float part[4][64];
+    const int grow = blockIdx.x, yy = blockIdx.y, tx = threadIdx.x, ty = threadIdx.y;
+    const TableGradDesc& t = a.t[tg_find(a, grow)];
+    const int row = grow - a.row0[tg_find(a, grow)];
+    const bool second = yy >= TG_SEG;
+    const int32_t* ptr = second ? t.ptr2 : t.ptr1;
+    if (!ptr) return;
+    const int32_t* idx = second ? t.idx2 : t.idx1;
+    const float* src = second ? t.src2 : t.src1;
+    const int ld = second ? t.ld2 : t.ld1, off = second ? t.off2 : t.off1;
+    const int y = second ? yy - TG_SEG : yy;
+    const int b = ptr[row], e = ptr[row + 1], per = (e - b + TG_SEG - 1) / TG_SEG;
+    const int k0 = b + y * per, k1 = min(e, k0 + per);
+    if (k0 >= k1) return;                       // block-uniform: empty segment, nothing written
+    const int q = (k1 - k0 + 3) / 4;
+    const int ka = min(k1, k0 + ty * q), kb = min(k1, ka + q);
+    float* out = a.partial + ((long long)grow * (2 * TG_SEG) + yy) * a.dmax;
+    for (int c0 = 0; c0 < t.D; c0 += 64) {
         const int c = c0 + tx;
         float s = 0.f;
-        if (c < D) {
-            {
-                const int b = ptr1[row], e = ptr1[row + 1], len = e - b, per = (len + TG_Y - 1) / TG_Y;
-                const int k0 = b + ty * per, k1 = min(e, k0 + per);
-                for (int k = k0; k < k1; ++k) s += src1[(long long)idx1[k] * ld1 + off1 + c];
+        if (c < t.D) {
+            int k = ka;
+            for (; k + 4 <= kb; k += 4) {
+                const int j0 = idx[k], j1 = idx[k + 1], j2 = idx[k + 2], j3 = idx[k + 3];
+                const float v0 = src[(long long)j0 * ld + off + c], v1 = src[(long long)j1 * ld + off + c];
+                const float v2 = src[(long long)j2 * ld + off + c], v3 = src[(long long)j3 * ld + off + c];
+                s = (((s + v0) + v1) + v2) + v3;
             }
-            if (ptr2) {
-                const int b = ptr2[row], e = ptr2[row + 1], len = e - b, per = (len + TG_Y - 1) / TG_Y;
-                const int k0 = b + ty * per, k1 = min(e, k0 + per);
-                float s2 = 0.f;
-                for (int k = k0; k < k1; ++k) s2 += src2[(long long)idx2[k] * ld2 + off2 + c];
-                s += s2;
-            }
+            for (; k < kb; ++k) s += src[(long long)idx[k] * ld + off + c];
         }
         part[ty][tx] = s;
         __syncthreads();
-        if (ty == 0 && c < D) {
-            float v = 0.f;
-#pragma unroll
-            for (int y = 0; y < TG_Y; ++y) v += part[y][tx];
-            dtable[(long long)row * D + c] = v;
-        }
+        if (ty == 0 && c < t.D) out[c] = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(128) void table_grad_final_kernel(const TableArgs a) {
+    const int grow = blockIdx.x;
+    const int ti = tg_find(a, grow);
+    const TableGradDesc& t = a.t[ti];
+    const int row = grow - a.row0[ti];
+    const int len1 = t.ptr1[row + 1] - t.ptr1[row], per1 = (len1 + TG_SEG - 1) / TG_SEG;
+    const int len2 = t.ptr2 ? t.ptr2[row + 1] - t.ptr2[row] : 0, per2 = (len2 + TG_SEG - 1) / TG_SEG;
+    const float* in = a.partial + (long long)grow * (2 * TG_SEG) * a.dmax;
+    for (int c = threadIdx.x; c < t.D; c += blockDim.x) {
+        float v = 0.f;
+        for (int y = 0; y < TG_SEG && y * per1 < len1; ++y) v += in[(long long)y * a.dmax + c];
+        for (int y = 0; y < TG_SEG && y * per2 < len2; ++y) v += in[(long long)(TG_SEG + y) * a.dmax + c];
+        t.dtable[(long long)row * t.D + c] = v;
     }
 }
 
@@ -292,6 +370,9 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     a.ldx = ldx; a.ldo = ldo; a.n = n; a.H4 = H / 4;
     const long long items = (long long)n * a.H4;
     dim3 grid((unsigned)((items + 255) / 256), ngroups);
+    double bytes = 0;
+    for (int k = 0; k < ngroups; ++k) bytes += 2.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1);
+    ProfScope prof(s, KC_AGG_FWD, bytes);
     hipLaunchKernelGGL(gine_agg_fwd_kernel, grid, dim3(256), 0, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
@@ -313,6 +394,9 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     a.ldda = ldda; a.ldx = ldx; a.lddx = lddx; a.ldp = ldp; a.n = n; a.H4 = H / 4; a.node_graph = node_graph;
     const long long items = (long long)n * a.H4;
     dim3 grid((unsigned)((items + 255) / 256), ngroups);
+    double bytes = 0;
+    for (int k = 0; k < ngroups; ++k) bytes += g[k].da ? 3.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1) : 2.0 * n * 4 * H;
+    ProfScope prof(s, KC_AGG_BWD, bytes);
     hipLaunchKernelGGL(gine_agg_bwd_kernel, grid, dim3(256), 0, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
@@ -325,9 +409,10 @@ int gine_etab_grad(hipStream_t s, const EtabGroup* g, int ngroups, int t, int ld
     for (int k = 0; k < ngroups; ++k) a.g[k] = g[k];
     if (ngroups == 1) a.g[1] = g[0];
     a.t = t; a.ldda = ldda; a.ldx = ldx; a.n = n; a.H4 = H / 4; a.chunks = chunks;
-    hipLaunchKernelGGL(gine_etab_partial_kernel, dim3(chunks, t, ngroups), dim3(128), 0, s, a);
+    ProfScope prof(s, KC_ETAB, (double)ngroups * t * 2.0 * n * 4 * H);
+    hipLaunchKernelGGL(gine_etab_partial_kernel, dim3(chunks, t, ngroups), dim3(64, 4), 0, s, a);
     PSVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gine_etab_final_kernel, dim3((H + 255) / 256, ngroups), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gine_etab_final_kernel, dim3((H / 4 + 63) / 64, ngroups), dim3(64, 8), 0, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -335,6 +420,7 @@ int gine_etab_grad(hipStream_t s, const EtabGroup* g, int ngroups, int t, int ld
 int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32_t* q, const float* ta,
                   const float* tp, const float* tq, int da, int dp, int dq, float* out, int n) {
     if (n == 0) return 0;
+    ProfScope prof(s, KC_EMBED, (double)n * (12 + 4.0 * (da + dp + dq)));
     hipLaunchKernelGGL(embed3_gather_kernel, dim3(grid_for((long long)n * (da + dp + dq), 256)), dim3(256), 0, s,
                        a, p, q, ta, tp, tq, da, dp, dq, out, n);
     PSVAE_LAUNCH_CHECK();
@@ -344,18 +430,38 @@ int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32
 int rows_gather(hipStream_t s, const int32_t* idx, int /*idx_stride_outer*/, int inner, int idx_ld, const float* table,
                 int width, float* out, int rows) {
     if (rows == 0) return 0;
+    ProfScope prof(s, KC_EMBED, (double)rows * (4 + 4.0 * width));
     hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for((long long)rows * width, 256)), dim3(256), 0, s,
                        idx, inner, idx_ld, table, width, out, rows);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
 
-int table_grad(hipStream_t s, float* dtable, int rows, int D, const int32_t* ptr1, const int32_t* idx1,
-               const float* src1, int ld1, int off1, const int32_t* ptr2, const int32_t* idx2, const float* src2,
-               int ld2, int off2) {
-    if (rows == 0 || D == 0) return 0;
-    hipLaunchKernelGGL(table_grad_kernel, dim3(rows), dim3(TG_X, TG_Y), 0, s, dtable, D, ptr1, idx1, src1, ld1, off1,
-                       ptr2, idx2, src2, ld2, off2);
+size_t table_grads_scratch(const TableGradDesc* t, int nt) {
+    size_t rows = 0; int dmax = 0;
+    for (int k = 0; k < nt; ++k) { rows += t[k].rows; if (t[k].D > dmax) dmax = t[k].D; }
+    return rows * 2 * TG_SEG * (size_t)dmax;
+}
+
+int table_grads(hipStream_t s, const TableGradDesc* t, int nt, float* partial, size_t partial_floats) {
+    if (nt < 1 || nt > 3) return PSVAE_E_SHAPE;
+    if (!partial || partial_floats < table_grads_scratch(t, nt)) return PSVAE_E_WORKSPACE;
+    TableArgs a;
+    int rows = 0, dmax = 0, any2 = 0;
+    double bytes = 0;
+    for (int k = 0; k < nt; ++k) {
+        if (!t[k].dtable || !t[k].ptr1 || !t[k].idx1 || !t[k].src1) return PSVAE_E_NULL;
+        a.t[k] = t[k]; a.row0[k] = rows; rows += t[k].rows;
+        if (t[k].D > dmax) dmax = t[k].D;
+        if (t[k].ptr2) any2 = 1;
+        bytes += (double)t[k].rows * t[k].D * 4.0;
+    }
+    a.row0[nt] = rows; a.nt = nt; a.dmax = dmax; a.partial = partial;
+    if (rows == 0 || dmax == 0) return 0;
+    ProfScope prof(s, KC_TABLE_GRAD, bytes);
+    hipLaunchKernelGGL(table_grad_partial_kernel, dim3(rows, any2 ? 2 * TG_SEG : TG_SEG), dim3(64, 4), 0, s, a);
+    PSVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(table_grad_final_kernel, dim3(rows), dim3(128), 0, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -365,6 +471,7 @@ int segment_pool_fwd(hipStream_t s, const float* x, int ldx, const int32_t* grap
     if (B == 0) return 0;
     if (width % 4 || ldx % 4 || ldp % 4 || !aligned16(x) || !aligned16(pooled)) return PSVAE_E_ALIGN;
     const int W4 = width / 4;
+    ProfScope prof(s, KC_POOL, 4.0 * width * (graph_off ? 1 : 1) * (double)B);
     hipLaunchKernelGGL(segment_pool_kernel, dim3((W4 + 255) / 256, B), dim3(256), 0, s, x, ldx, graph_off, pooled, ldp, W4);
     PSVAE_LAUNCH_CHECK();
     return 0;
@@ -374,6 +481,7 @@ int pair_gather(hipStream_t s, const float* emb, int lde, const float* z, const 
                 const int32_t* graph, float* out, int S, int H, int Z) {
     if (S == 0) return 0;
     if (H % 4 || Z % 4 || lde % 4 || !aligned16(emb) || !aligned16(z) || !aligned16(out)) return PSVAE_E_ALIGN;
+    ProfScope prof(s, KC_PAIR_GATHER, (double)S * 4.0 * (2 * H + Z) * 2);
     hipLaunchKernelGGL(pair_gather_kernel, dim3(grid_for((long long)S * (2 * H + Z) / 4, 256)), dim3(256), 0, s,
                        emb, lde, z, src, dst, graph, out, S, H / 4, Z / 4);
     PSVAE_LAUNCH_CHECK();
@@ -386,6 +494,7 @@ int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_
     if (H % 4 || Z % 4 || P % 4 || ldde % 4) return PSVAE_E_ALIGN;
     const long long items = (long long)n * (H / 4) + (long long)B * (Z / 4);
     if (items == 0) return 0;
+    ProfScope prof(s, KC_PAIR_SCATTER, (double)items * 16.0 * 2);
     hipLaunchKernelGGL(pair_scatter_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, dpin, P, by_src_ptr,
                        by_src_idx, by_dst_ptr, by_dst_idx, pair_graph_off, demb, ldde, dz, dz_accumulate, n, B, H / 4, Z / 4);
     PSVAE_LAUNCH_CHECK();
@@ -394,6 +503,7 @@ int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_
 
 int fill_zero(hipStream_t s, float* p, int64_t count) {
     if (count <= 0) return 0;
+    ProfScope prof(s, KC_HEAD, 4.0 * count);
     hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(count, 256)), dim3(256), 0, s, p, (long long)count);
     PSVAE_LAUNCH_CHECK();
     return 0;

@@ -50,15 +50,26 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
             const float* wu = wr + (long long)R * R;
             const float* wn = wu + (long long)R * R;
             floatx4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar, an = ar;
-            for (int m = 0; m < ntiles; ++m) {
+            // W_hh fragments are fetched two K-groups ahead of the MFMAs that consume them
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto wload = [&](const float* w, int m) -> float4 {
                 const int k = 16 * m + 4 * kq;
+                return (uok && m < ntiles && k < R) ? *reinterpret_cast<const float4*>(w + k) : zero4;
+            };
+            float4 br = wload(wr, 0), bu = wload(wu, 0), bn = wload(wn, 0);
+            float4 br1 = wload(wr, 1), bu1 = wload(wu, 1), bn1 = wload(wn, 1);
+            // this lane's input-gate terms for the step (consumed after the MFMA loop)
+            float gir[4], giu[4], gin[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int b = b0 + kq * 4 + reg;
+                const bool ok = uok && b < B;
+                const float* g = gi + ((long long)(ok ? b : 0) * T + t) * 3 * R;
+                gir[reg] = ok ? g[unit] : 0.f; giu[reg] = ok ? g[R + unit] : 0.f; gin[reg] = ok ? g[2 * R + unit] : 0.f;
+            }
+            for (int m = 0; m < ntiles; ++m) {
+                const float4 br2 = wload(wr, m + 2), bu2 = wload(wu, m + 2), bn2 = wload(wn, m + 2);
                 const float4 a = *reinterpret_cast<const float4*>(&cur[((4 * m + kq) * ROWS + j) << 2]);
-                float4 br = make_float4(0.f, 0.f, 0.f, 0.f), bu = br, bn = br;
-                if (uok && k < R) {
-                    br = *reinterpret_cast<const float4*>(wr + k);
-                    bu = *reinterpret_cast<const float4*>(wu + k);
-                    bn = *reinterpret_cast<const float4*>(wn + k);
-                }
                 ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, br.x, ar, 0, 0, 0);
                 au = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bu.x, au, 0, 0, 0);
                 an = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bn.x, an, 0, 0, 0);
@@ -71,6 +82,8 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
                 ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, br.w, ar, 0, 0, 0);
                 au = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bu.w, au, 0, 0, 0);
                 an = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bn.w, an, 0, 0, 0);
+                br = br1; bu = bu1; bn = bn1;
+                br1 = br2; bu1 = bu2; bn1 = bn2;
             }
             if (uok) {
                 const float cr = bhh[unit], cu = bhh[R + unit], cn = bhh[2 * R + unit];
@@ -80,11 +93,10 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
                     float hn = 0.f;
                     if (b < B) {
                         const long long base = (long long)b * T + t;
-                        const float* g = gi + base * 3 * R;
                         const float ghn = an[reg] + cn;
-                        const float r = sigmoidf_(g[unit] + ar[reg] + cr);
-                        const float u = sigmoidf_(g[R + unit] + au[reg] + cu);
-                        const float c = tanhf(g[2 * R + unit] + r * ghn);
+                        const float r = sigmoidf_(gir[reg] + ar[reg] + cr);
+                        const float u = sigmoidf_(giu[reg] + au[reg] + cu);
+                        const float c = tanhf(gin[reg] + r * ghn);
                         const float hp = cur[tile_idx(unit, row)];
                         hn = (1.0f - u) * c + u * hp;
                         hseq[base * R + unit] = hn;
@@ -142,18 +154,28 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
             const int kcol = tile * 16 + j;
             const bool kok = kcol < R;
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int m = 0; m < msteps; ++m) {
+            // W_hh rows are fetched two K-groups ahead of the MFMAs that consume them
+            auto wload = [&](int m) -> float4 {
                 const int jb = 16 * m + 4 * kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kok && m < msteps) {
+                    const float* w = whh + (long long)jb * R + kcol;
+                    if (jb < G) v.x = w[0];
+                    if (jb + 1 < G) v.y = w[R];
+                    if (jb + 2 < G) v.z = w[2 * R];
+                    if (jb + 3 < G) v.w = w[3 * R];
+                }
+                return v;
+            };
+            float4 w0 = wload(0), w1 = wload(1);
+            for (int m = 0; m < msteps; ++m) {
+                const float4 w2 = wload(m + 2);
                 const float4 a = *reinterpret_cast<const float4*>(&sG[((4 * m + kq) * ROWS + j) << 2]);
-                const float* w = whh + (long long)jb * R + kcol;
-                const float w0 = (kok && jb < G) ? w[0] : 0.f;
-                const float w1 = (kok && jb + 1 < G) ? w[R] : 0.f;
-                const float w2 = (kok && jb + 2 < G) ? w[2 * R] : 0.f;
-                const float w3 = (kok && jb + 3 < G) ? w[3 * R] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0.w, acc, 0, 0, 0);
+                w0 = w1; w1 = w2;
             }
             if (kok) {
 #pragma unroll
@@ -178,6 +200,7 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
     const size_t lds = (size_t)2 * R16 * ROWS * sizeof(float);
     if (lds > 64 * 1024) return PSVAE_E_SHAPE;
     const int nwaves = ntiles < 16 ? ntiles : 16;
+    ProfScope prof(s, KC_GRU_FWD, 2.0 * B * T * 3 * R * R);
     hipLaunchKernelGGL(gru_fwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(64 * nwaves), lds, s, gi, h0, whh, bhh, hseq,
                        hprev, gates, B, T, R);
     PSVAE_LAUNCH_CHECK();
@@ -192,6 +215,7 @@ int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* 
     const size_t lds = (size_t)(ROWS * R16 + ROWS * G16) * sizeof(float);
     if (lds > 64 * 1024) return PSVAE_E_SHAPE;
     const int nwaves = ntiles < 16 ? ntiles : 16;
+    ProfScope prof(s, KC_GRU_BWD, 2.0 * B * T * 3 * R * R);
     hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(64 * nwaves), lds, s, dhseq, hprev, gates, whh,
                        dgi, dgh, dh0, B, T, R);
     PSVAE_LAUNCH_CHECK();

@@ -189,14 +189,18 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
 
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z) {
     if (B == 0) return 0;
+    { ProfScope prof(s, KC_HEAD, 0);
     hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mulv, eps, z, klrow, B, Z);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
 int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz, const float* gscale,
                  const float* denoms, float* dmulv, int B, int Z) {
     if (B == 0) return 0;
+    { ProfScope prof(s, KC_HEAD, 0);
     hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, s, mulv, eps, dz, gscale, denoms, dmulv, B, Z);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -204,8 +208,10 @@ int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* ta
                    int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse) {
     if (rows == 0) return 0;
     if (rows_per_group < 1) return PSVAE_E_SHAPE;
+    { ProfScope prof(s, KC_CE, 4.0 * rows * classes);
     hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, ld, target, tstride, toffset,
                        rows_per_group, rows, classes, ignore_index, row_loss, lse);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -216,27 +222,35 @@ int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* ta
     long long total = (long long)rows * classes;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    { ProfScope prof(s, KC_CE, 8.0 * rows * classes);
     hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3(blocks), dim3(256), 0, s, logits_inout, ld, target, tstride, toffset,
                        rows_per_group, rows, classes, ignore_index, lse, gscale, gidx, denoms, didx);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
 int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float* row, int B, int P) {
     if (B == 0) return 0;
+    { ProfScope prof(s, KC_HEAD, 0);
     hipLaunchKernelGGL(mse_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, pred, ldp, gold, row, B, P);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
 int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const float* gscale, const float* denoms,
             float* dpred, int B, int P) {
     if (B == 0) return 0;
+    { ProfScope prof(s, KC_HEAD, 0);
     hipLaunchKernelGGL(mse_bwd_kernel, dim3((B * P + 255) / 256), dim3(256), 0, s, pred, ldp, gold, gscale, denoms, dpred, B, P);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
 int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* piece_row, int rows_p,
                     const float* edge_row, int S, const float* klrow, const float* denoms, float* losses) {
+    { ProfScope prof(s, KC_HEAD, 0);
     hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(256), 0, s, mse_row, B, piece_row, rows_p, edge_row, S, klrow, denoms, losses);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -247,12 +261,16 @@ int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t cou
               float max_norm, float lr, float b1, float b2, float eps, float bias1, float bias2, float* norm_out) {
     if (count <= 0) return 0;
     if (!p || !g || !m || !v || !partials) return PSVAE_E_NULL;
+    { ProfScope prof(s, KC_ADAM, 4.0 * count);
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, g, (long long)count, partials);
+    }
     PSVAE_LAUNCH_CHECK();
     int blocks = (int)((count + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    { ProfScope prof(s, KC_ADAM, 28.0 * count);
     hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, (long long)count, partials, max_norm, lr,
                        b1, b2, eps, bias1, bias2, norm_out);
+    }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -19,6 +19,17 @@
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// ---------------------------------------------------------------- launch timer (profiler.hip)
+enum KernelClass {
+    KC_GEMM_FWD = 0, KC_GEMM_DX, KC_GEMM_DW, KC_GEMM_REDUCE, KC_AGG_FWD, KC_AGG_BWD, KC_ETAB, KC_EMBED, KC_TABLE_GRAD,
+    KC_POOL, KC_PAIR_GATHER, KC_PAIR_SCATTER, KC_GRU_FWD, KC_GRU_BWD, KC_CE, KC_HEAD, KC_ADAM, KC_COUNT
+};
+struct ProfScope {
+    ProfScope(hipStream_t s, int kc, double work);
+    ~ProfScope();
+    hipStream_t s_; int idx_;
+};
+
 // ---------------------------------------------------------------- GEMM family
 // C[i][j] (+)= epilogue( sum_r A(i,r) * B(j,r) ), fp32 in / fp32 accumulate on
 // v_mfma_f32_32x32x2_f32.  A(i,r) = A[i*lda + r] or, when a_t, A[r*lda + i]
@@ -58,6 +69,7 @@ struct AggGroup {  // one GINE stack (encoder or decoder-side encoder)
     const int32_t *rowptr, *col, *etype;
     const float *edge_w, *edge_b;
     float ope;                            // 1 + eps
+    int E;                                // edge count (work accounting only)
 };
 int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo, int n, int H);
 struct AggBwdGroup {
@@ -68,6 +80,7 @@ struct AggBwdGroup {
     const float *edge_w, *edge_b;
     float ope;
     const float* dpool;     // [B, ldp] slice start, or null
+    int E;                  // edge count (work accounting only)
 };
 int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int ldx, int lddx, int ldp,
                  const int32_t* node_graph, int n, int H);
@@ -80,16 +93,20 @@ struct EtabGroup {
     float* partial;                       // scratch [t*chunks][4][H]
 };
 int gine_etab_grad(hipStream_t s, const EtabGroup* g, int ngroups, int t, int ldda, int ldx, int n, int H, int chunks);
-static inline int etab_chunks(int n) { int c = (n + 127) / 128; return c < 1 ? 1 : (c > 64 ? 64 : c); }
+static inline int etab_chunks(int n) { int c = (n + 31) / 32; return c < 1 ? 1 : (c > 512 ? 512 : c); }
 
 int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32_t* q, const float* ta,
                   const float* tp, const float* tq, int da, int dp, int dq, float* out, int n);
 int rows_gather(hipStream_t s, const int32_t* idx, int idx_stride_outer, int inner, int idx_ld, const float* table,
                 int width, float* out, int rows);
-// dTable[row] = sum over list1 of src1[idx, off1 .. off1+D) + sum over list2 of src2[idx, off2 ..)
-int table_grad(hipStream_t s, float* dtable, int rows, int D, const int32_t* ptr1, const int32_t* idx1,
-               const float* src1, int ld1, int off1, const int32_t* ptr2, const int32_t* idx2, const float* src2,
-               int ld2, int off2);
+// dTable[row] = sum over list 1 of src1[idx, off1 .. off1+D) + sum over list 2 of src2[idx, off2 ..)
+struct TableGradDesc {
+    float* dtable; int rows, D;
+    const int32_t *ptr1, *idx1; const float* src1; int ld1, off1;
+    const int32_t *ptr2, *idx2; const float* src2; int ld2, off2;   // ptr2 may be null
+};
+size_t table_grads_scratch(const TableGradDesc* t, int ntables);
+int table_grads(hipStream_t s, const TableGradDesc* t, int ntables, float* partial, size_t partial_floats);
 int segment_pool_fwd(hipStream_t s, const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
                      int B, int width);
 int pair_gather(hipStream_t s, const float* emb, int lde, const float* z, const int32_t* src, const int32_t* dst,

@@ -14,7 +14,7 @@ namespace {
 
 struct Sz {
     int B, n, S, L, T, BT;
-    int Da, Dp, Dq, Din, H, G, Z, R, V2, P, P2, Hp, NP, te, td;
+    int Da, Dp, Dq, Din, H, G, Z, R, V2, P, P2, Hp, NP, te, td, NA, MP;
     int ldl, ldpred;
 };
 
@@ -24,7 +24,7 @@ Sz sizes(const psvae_dims& d, const psvae_batch& b) {
     s.Da = d.d_atom; s.Dp = d.d_piece; s.Dq = d.d_pos; s.Din = s.Da + s.Dp + s.Dq;
     s.H = d.hidden; s.G = d.graph; s.Z = d.latent; s.R = d.rnn;
     s.V2 = d.num_piece; s.P = 2 * d.hidden + d.latent; s.P2 = s.P / 2; s.Hp = d.pred_hidden; s.NP = d.n_props;
-    s.te = d.t_enc; s.td = d.t_dec;
+    s.te = d.t_enc; s.td = d.t_dec; s.NA = d.num_atom; s.MP = d.max_pos;
     s.ldl = (int)round_up(s.V2, 4); s.ldpred = (int)round_up(s.NP, 4);
     return s;
 }
@@ -47,6 +47,7 @@ struct WS {
     // backward
     float *dpred, *dq2, *dq1, *dz, *dhseq, *dgi, *dgh, *dh0, *dsemb, *ds3, *ds2, *ds1, *dpin;
     float *dmulv, *dcond, *dpooled, *GE, *GD, *G0, *DHE, *DHD, *DAE, *DAD, *dX0, *etab_part;
+    float *tg_part; size_t tg_part_floats;
     float *scratch; size_t scratch_floats;
     size_t total_floats;
 };
@@ -61,8 +62,10 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
     auto upw = [&](size_t rows, size_t cols) { if (rows * (cols + 1) > maxw) maxw = rows * (cols + 1); };
     upw(s.H, s.Din); upw(2 * s.H, s.Din); upw(s.G, s.te * s.H); upw(s.V2, s.R); upw(3 * s.R, s.R); upw(3 * s.R, s.Dp);
     upw(s.P2, s.P); upw(s.P, s.P2); upw(s.P2, s.P2); upw(2 * s.Z, s.G); upw(s.Hp, s.Hp); upw(s.Hp, s.Z); upw(s.R, s.Z);
-    const size_t scratch = ((size_t)1 << 21) + tmax * maxw;
+    const size_t scratch = ((size_t)6 << 20) + tmax * maxw;
     const size_t chunks = etab_chunks(s.n);
+    const int dmax = s.Da > s.Dp ? (s.Da > s.Dq ? s.Da : s.Dq) : (s.Dp > s.Dq ? s.Dp : s.Dq);
+    const size_t tg_part = (size_t)(s.NA + s.V2 + s.MP) * 32 * dmax;
     const Field f[] = {
         {"x0", &WS::X0, n * s.Din},
         {"enc_stack", &WS::XE, n * (s.te + 1) * H}, {"dec_stack", &WS::XD, n * (s.td + 1) * H},
@@ -87,6 +90,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         {"enc_dhid", &WS::DHE, n * s.te * H}, {"dec_dhid", &WS::DHD, n * s.td * H},
         {"enc_dagg", &WS::DAE, n * s.te * H}, {"dec_dagg", &WS::DAD, n * s.td * H},
         {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * tmax * chunks * 4 * H},
+        {"table_grad_part", &WS::tg_part, tg_part},
         {"scratch", &WS::scratch, scratch},
     };
     size_t off = 0;
@@ -95,7 +99,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         if (want && want_off && strcmp(want, e.name) == 0) *want_off = (int64_t)off;
         off += (size_t)round_up((int64_t)(e.count ? e.count : 1), 64);
     }
-    if (w) { w->scratch_floats = scratch; w->total_floats = off; }
+    if (w) { w->scratch_floats = scratch; w->tg_part_floats = tg_part; w->total_floats = off; }
     return off;
 }
 
@@ -104,7 +108,7 @@ struct Stack {  // one GINE stack
     const int32_t *rowptr, *col, *etype, *rowptr_t, *col_t, *etype_t;
     const float *node_w, *node_b, *edge_w, *edge_b, *w1, *b1, *w2, *b2;
     float *g_node_w, *g_node_b, *g_edge_w, *g_edge_b, *g_w1, *g_b1, *g_w2, *g_b2;
-    float ope; int t;
+    float ope; int t; int E;
 };
 
 Stack enc_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* g, const psvae_batch& b, const WS& w) {
@@ -115,7 +119,7 @@ Stack enc_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
     k.w1 = p.enc_w1; k.b1 = p.enc_b1; k.w2 = p.enc_w2; k.b2 = p.enc_b2;
     if (g) { k.g_node_w = g->enc_node_w; k.g_node_b = g->enc_node_b; k.g_edge_w = g->enc_edge_w; k.g_edge_b = g->enc_edge_b;
              k.g_w1 = g->enc_w1; k.g_b1 = g->enc_b1; k.g_w2 = g->enc_w2; k.g_b2 = g->enc_b2; }
-    k.ope = 1.0f + d.eps_enc; k.t = d.t_enc;
+    k.ope = 1.0f + d.eps_enc; k.t = d.t_enc; k.E = b.E;
     return k;
 }
 Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* g, const psvae_batch& b, const WS& w) {
@@ -127,7 +131,7 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
     k.w1 = p.dec_w1; k.b1 = p.dec_b1; k.w2 = p.dec_w2; k.b2 = p.dec_b2;
     if (g) { k.g_node_w = g->dec_node_w; k.g_node_b = g->dec_node_b; k.g_edge_w = g->dec_edge_w; k.g_edge_b = g->dec_edge_b;
              k.g_w1 = g->dec_w1; k.g_b1 = g->dec_b1; k.g_w2 = g->dec_w2; k.g_b2 = g->dec_b2; }
-    k.ope = 1.0f + d.eps_dec; k.t = d.t_dec;
+    k.ope = 1.0f + d.eps_dec; k.t = d.t_dec; k.E = b.E_in;
     return k;
 }
 
@@ -147,7 +151,7 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
         AggGroup ag[2];
         for (int q = 0; q < ng; ++q)
             ag[q] = AggGroup{k[q].X + (size_t)l * H, k[q].A + (size_t)l * n * H, k[q].rowptr, k[q].col, k[q].etype,
-                             k[q].edge_w, k[q].edge_b, k[q].ope};
+                             k[q].edge_w, k[q].edge_b, k[q].ope, k[q].E};
         PSVAE_TRY(gine_agg_fwd(st, ag, ng, ldx, H, n, H));
         GemmDesc d1;
         d1.A = k[0].A + (size_t)l * n * H; d1.lda = H; d1.B = k[0].w1; d1.ldb = H; d1.C = k[0].Hid + (size_t)l * n * H; d1.ldc = H;
@@ -194,7 +198,7 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
             float* dx = l > 0 ? k[q].Gr + (size_t)l * nH : w.G0 + (size_t)(g0_slot0 + q) * H;
             const float* dp = (l > 0 && dpool && dpool[q]) ? dpool[q] + (size_t)(l - 1) * H : nullptr;
             ag[q] = AggBwdGroup{k[q].DA + (size_t)l * nH, k[q].X + (size_t)l * H, dx, k[q].rowptr_t, k[q].col_t,
-                                k[q].etype_t, k[q].edge_w, k[q].edge_b, k[q].ope, dp};
+                                k[q].etype_t, k[q].edge_w, k[q].edge_b, k[q].ope, dp, k[q].E};
         }
         PSVAE_TRY(gine_agg_bwd(st, ag, ng, H, ldx, l > 0 ? H : 2 * H, t * H, b.node_graph, n, H));
     }
@@ -362,7 +366,7 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
     {
         AggBwdGroup top{nullptr, nullptr, w.GE + (size_t)s.te * nH, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f,
-                        w.dpooled + (size_t)(s.te - 1) * s.H};
+                        w.dpooled + (size_t)(s.te - 1) * s.H, 0};
         PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
     }
     const float* dpool[2] = {w.dpooled, nullptr};
@@ -385,12 +389,12 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
         PSVAE_TRY(linear_bwd_x(st, w.G0 + s.H, 2 * s.H, p.dec_node_w, w.dX0, s.Din, s.n, s.H, s.Din, nullptr, 0, 1));
     }
     // --- embedding tables (piece table also receives the GRU-input gradient)
-    PSVAE_TRY(table_grad(st, g.atom_emb, d.num_atom, s.Da, b.atom_rows_ptr, b.atom_rows_idx, w.dX0, s.Din, 0,
-                         nullptr, nullptr, nullptr, 0, 0));
-    PSVAE_TRY(table_grad(st, g.piece_emb, d.num_piece, s.Dp, b.piece_rows_ptr, b.piece_rows_idx, w.dX0, s.Din, s.Da,
-                         b.seq_rows_ptr, b.seq_rows_idx, w.dsemb, s.Dp, 0));
-    PSVAE_TRY(table_grad(st, g.pos_emb, d.max_pos, s.Dq, b.pos_rows_ptr, b.pos_rows_idx, w.dX0, s.Din, s.Da + s.Dp,
-                         nullptr, nullptr, nullptr, 0, 0));
+    const TableGradDesc tg[3] = {
+        {g.atom_emb, d.num_atom, s.Da, b.atom_rows_ptr, b.atom_rows_idx, w.dX0, s.Din, 0, nullptr, nullptr, nullptr, 0, 0},
+        {g.piece_emb, d.num_piece, s.Dp, b.piece_rows_ptr, b.piece_rows_idx, w.dX0, s.Din, s.Da,
+         b.seq_rows_ptr, b.seq_rows_idx, w.dsemb, s.Dp, 0},
+        {g.pos_emb, d.max_pos, s.Dq, b.pos_rows_ptr, b.pos_rows_idx, w.dX0, s.Din, s.Da + s.Dp, nullptr, nullptr, nullptr, 0, 0}};
+    PSVAE_TRY(table_grads(st, tg, 3, w.tg_part, w.tg_part_floats));
     return 0;
 }
 

@@ -1,0 +1,61 @@
+"""Data-parallel training over the graphs of a batch: one process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI; "gloo" on CPU for tests).
+
+Exact global-batch semantics.  The three loss terms are means over different
+counts (non-pad target tokens, selected pairs, graphs), so averaging per-rank
+gradients would NOT equal the gradient of the global batch.  Instead every rank
+divides its local loss SUMS by the GLOBAL counts (the 4-float `denoms` vector of
+the batch is all-reduced before it is used) and the flat gradient buffers are
+all-reduced with SUM.  The result is independent of how graphs are dealt to
+ranks, up to fp32 summation order.
+
+The reference has no working multi-GPU path for this model (its Lightning 'dp'
+mode mis-splits the batch dict, `src/train.py:49-50`), so this file has no
+reference counterpart beyond "train on more GPUs".
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous slice of a global batch owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class GradReducer:
+    """All-reduce (sum) of a flat gradient buffer in a few large buckets.
+
+    `bounds` are bucket boundaries (element offsets) in the order the buckets
+    become final during backward; each bucket is one collective.  xGMI is a
+    point-to-point mesh and this message is only ~7.6 MB, so the transfer is
+    latency-bound: few big collectives, never per-parameter ones."""
+
+    def __init__(self, bounds, group=None):
+        self.bounds = list(bounds)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def reduce_denoms(self, local_denoms, out=None):
+        """Global loss denominators: sum of the per-rank counts."""
+        out = local_denoms.clone() if out is None else out.copy_(local_denoms)
+        if self.world > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def reduce_grads(self, flat_grads, async_op=False):
+        if self.world == 1:
+            return []
+        works = []
+        for lo, hi in zip(self.bounds[:-1], self.bounds[1:]):
+            if hi > lo:
+                works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return works if async_op else []
+
+
+def global_step_reference(loss_sums_per_rank, counts_per_rank):
+    """Host arithmetic of the scheme above (used by the CPU tests): per-rank loss sums and
+    counts -> the global mean each rank's scaled losses add up to."""
+    total = sum(counts_per_rank)
+    return sum(s / total for s in loss_sums_per_rank)
