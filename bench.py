@@ -107,8 +107,7 @@ def main():
             reducer.reduce_denoms(local_denoms[i % n_distinct], out=nb.denoms)
         eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
         opt.zero_grad()
-        pred, (rec, _piece, _edge, kl) = model(batch, eps=eps)
-        loss = model.weighted_loss(pred, rec, kl)
+        loss = model.training_step(batch, eps=eps)
         loss.backward()
         if world > 1:
             reducer.reduce_grads(model.flat_buffers()[1])
@@ -133,7 +132,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # roofline pass: same steps with every launch bracketed by HIP events on its stream
     L = _lib.lib()

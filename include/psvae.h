@@ -124,20 +124,25 @@ typedef struct psvae_batch {
  * psvae_step_forward  = PSVAEModel.forward (src/pl_models/ps_vae_model.py:33-58)
  *   incl. VAEPieceDecoder.forward (src/modules/vae_piece_decoder.py:71-117),
  *   Encoder.embed_node/embed_graph (src/modules/encoder.py:53-69), Predictor.forward
- *   (src/modules/predictor.py:19-21).  losses[0..4] = pred, rec, piece, edge, kl.
- * psvae_step_backward = what autograd derives from it; loss_grads[0..3] are the
- *   upstream gradients of (pred, piece, edge, kl) as DEVICE floats (rec's
- *   gradient is added to piece and edge by the caller).  Gradients are written
- *   (not accumulated) into `grads`.  The two unused parameters of the
+ *   (src/modules/predictor.py:19-21).  losses[0..5] (device) = pred, rec, piece, edge, kl, total,
+ *   where total = w[0]*pred + w[1]*rec + w[2]*kl is PSVAEModel.weighted_loss
+ *   (ps_vae_model.py:71-74) for the HOST array loss_weights = {1-alpha, alpha, beta}
+ *   (NULL: total = 0).
+ * psvae_step_backward = what autograd derives from it; loss_grads[0..5] are the
+ *   upstream gradients of those six outputs as DEVICE floats; pass the same
+ *   loss_weights.  Gradients are written (not accumulated) into `grads`.
+ *   Independent branches of the step run on two internal side streams that fork
+ *   from and join back into `stream` inside each call (PSVAE_STREAMS=0 disables).  The two unused parameters of the
  *   decoder-side encoder (its `linear`) have no field and get no gradient.
  * The workspace holds the saved activations: pass the same buffer, dims and
  * batch to forward and backward. */
 size_t psvae_workspace_bytes(const psvae_dims* dims, const psvae_batch* batch_sizes);
 int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
-                       void* workspace, size_t workspace_bytes, float* losses, void* stream);
+                       void* workspace, size_t workspace_bytes, const float* loss_weights, float* losses,
+                       void* stream);
 int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
-                        void* workspace, size_t workspace_bytes, const float* loss_grads,
-                        const psvae_params* grads, void* stream);
+                        void* workspace, size_t workspace_bytes, const float* loss_weights,
+                        const float* loss_grads, const psvae_params* grads, void* stream);
 /* Offsets (in floats) of named activations inside the workspace, for tests and
  * the module-level API.  Returns -1 for an unknown name. */
 int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_batch* batch_sizes, const char* name);

@@ -99,8 +99,8 @@ def lib():
     L.psvae_workspace_bytes.argtypes = [P(Dims), P(Batch)]
     L.psvae_workspace_offset.restype = i64
     L.psvae_workspace_offset.argtypes = [P(Dims), P(Batch), C.c_char_p]
-    L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp]
-    L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, P(Params), vp]
+    L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp]
+    L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp]
     L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
     L.psvae_adam_partials.restype = sz
     L.psvae_adam_partials.argtypes = [i64]

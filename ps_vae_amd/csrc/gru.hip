@@ -51,10 +51,11 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
             const float* wn = wu + (long long)R * R;
             floatx4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar, an = ar;
             // W_hh fragments are fetched two K-groups ahead of the MFMAs that consume them
-            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            // (unconditional loads at a clamped address: a branch around a load would drain the
+            // load queue; columns k >= R meet zeros of the hidden tile, rows of units >= R are discarded)
             auto wload = [&](const float* w, int m) -> float4 {
-                const int k = 16 * m + 4 * kq;
-                return (uok && m < ntiles && k < R) ? *reinterpret_cast<const float4*>(w + k) : zero4;
+                const int k = min(16 * m + 4 * kq, R - 4);
+                return *reinterpret_cast<const float4*>(w + k);
             };
             float4 br = wload(wr, 0), bu = wload(wu, 0), bn = wload(wn, 0);
             float4 br1 = wload(wr, 1), bu1 = wload(wu, 1), bn1 = wload(wn, 1);
@@ -63,9 +64,8 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int b = b0 + kq * 4 + reg;
-                const bool ok = uok && b < B;
-                const float* g = gi + ((long long)(ok ? b : 0) * T + t) * 3 * R;
-                gir[reg] = ok ? g[unit] : 0.f; giu[reg] = ok ? g[R + unit] : 0.f; gin[reg] = ok ? g[2 * R + unit] : 0.f;
+                const float* g = gi + ((long long)min(b, B - 1) * T + t) * 3 * R + (uok ? unit : 0);
+                gir[reg] = g[0]; giu[reg] = g[R]; gin[reg] = g[2 * R];   // unused when the row or unit is out of range
             }
             for (int m = 0; m < ntiles; ++m) {
                 const float4 br2 = wload(wr, m + 2), bu2 = wload(wu, m + 2), bn2 = wload(wn, m + 2);
@@ -156,16 +156,11 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
             // W_hh rows are fetched two K-groups ahead of the MFMAs that consume them
             auto wload = [&](int m) -> float4 {
-                const int jb = 16 * m + 4 * kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kok && m < msteps) {
-                    const float* w = whh + (long long)jb * R + kcol;
-                    if (jb < G) v.x = w[0];
-                    if (jb + 1 < G) v.y = w[R];
-                    if (jb + 2 < G) v.z = w[2 * R];
-                    if (jb + 3 < G) v.w = w[3 * R];
-                }
-                return v;
+                // unconditional loads at clamped addresses (rows >= G meet zeros of the d(gh) tile,
+                // columns >= R are discarded): no branch may sit between a load and its use
+                const int jb = min(16 * m + 4 * kq, G - 4);
+                const float* w = whh + (long long)jb * R + min(kcol, R - 1);
+                return make_float4(w[0], w[R], w[2 * R], w[3 * R]);
             };
             float4 w0 = wload(0), w1 = wload(1);
             for (int m = 0; m < msteps; ++m) {

@@ -6,24 +6,28 @@
 
 namespace {
 
-// rsample (src/modules/vae_piece_decoder.py:56-63): thread per graph.
-__global__ void vae_head_fwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, float* __restrict__ z,
-                                    float* __restrict__ klrow, int B, int Z) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// rsample (src/modules/vae_piece_decoder.py:56-63): one wave per graph, lanes over the latent
+// dimensions; the KL terms are reduced across the wave with a fixed shuffle tree.
+__global__ __launch_bounds__(256) void vae_head_fwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
+                                                           float* __restrict__ z, float* __restrict__ klrow, int B, int Z) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const float* mu = mulv + (long long)b * 2 * Z;
     const float* raw = mu + Z;
     float s = 0.f;
-    for (int k = 0; k < Z; ++k) {
+    for (int k = lane; k < Z; k += 64) {
         const float m = mu[k], lv = -fabsf(raw[k]);
         s += 1.0f + lv - m * m - expf(lv);
         z[(long long)b * Z + k] = m + expf(lv * 0.5f) * eps[(long long)b * Z + k];
     }
-    klrow[b] = s;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) klrow[b] = s;
 }
 
-// d(mean | raw log-var) from dz and the KL term; gscale[3] = dL/dkl, denoms[2] = B.
-__global__ void vae_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
+// d(mean | raw log-var) from dz (the sum of up to three partial gradients, added in a fixed
+// order) and the KL term; gscale[3] = dL/dkl, denoms[2] = B.
+__global__ void vae_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz0,
+                                    const float* __restrict__ dz1, const float* __restrict__ dz2,
                                     const float* __restrict__ gscale, const float* __restrict__ denoms,
                                     float* __restrict__ dmulv, int B, int Z) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -31,12 +35,26 @@ __global__ void vae_head_bwd_kernel(const float* __restrict__ mulv, const float*
     const int b = t / Z, k = t - b * Z;
     const float gk = gscale[3] / denoms[2];
     const float m = mulv[(long long)b * 2 * Z + k], raw = mulv[(long long)b * 2 * Z + Z + k];
-    const float lv = -fabsf(raw), d = dz[t];
+    float d = dz0[t];
+    if (dz1) d += dz1[t];
+    if (dz2) d += dz2[t];
+    const float lv = -fabsf(raw);
     const float dmu = d + gk * m;
     const float dlv = d * eps[t] * 0.5f * expf(lv * 0.5f) + gk * (-0.5f) * (1.0f - expf(lv));
     const float sgn = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
     dmulv[(long long)b * 2 * Z + k] = dmu;
     dmulv[(long long)b * 2 * Z + Z + k] = -sgn * dlv;
+}
+
+// Upstream gradients of the four loss terms from the gradient of the 6 outputs
+// [pred, rec, piece, edge, kl, total] with total = w[0] pred + w[1] rec + w[2] kl, rec = piece + edge.
+__global__ void make_gscale_kernel(const float* __restrict__ g, float w_pred, float w_rec, float w_kl, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = g[0] + g[5] * w_pred;
+        out[1] = g[2] + g[1] + g[5] * w_rec;
+        out[2] = g[3] + g[1] + g[5] * w_rec;
+        out[3] = g[4] + g[5] * w_kl;
+    }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -126,7 +144,8 @@ __device__ float block_sum_256(const float* __restrict__ v, int n, float* sh) {
 // losses = [pred, rec, piece, edge, kl]
 __global__ __launch_bounds__(256) void losses_finalize_kernel(const float* mse_row, int B, const float* piece_row, int rows_p,
                                                               const float* edge_row, int S, const float* klrow,
-                                                              const float* denoms, float* losses) {
+                                                              const float* denoms, float w_pred, float w_rec, float w_kl,
+                                                              float* losses) {
     __shared__ float sh[256];
     const float mse = block_sum_256(mse_row, B, sh);
     const float piece = block_sum_256(piece_row, rows_p, sh);
@@ -139,6 +158,7 @@ __global__ __launch_bounds__(256) void losses_finalize_kernel(const float* mse_r
         losses[2] = pl;
         losses[3] = el;
         losses[4] = -0.5f * kl / denoms[2];
+        losses[5] = w_rec * losses[1] + w_pred * losses[0] + w_kl * losses[4];
     }
 }
 
@@ -190,16 +210,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z) {
     if (B == 0) return 0;
     { ProfScope prof(s, KC_HEAD, 0);
-    hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mulv, eps, z, klrow, B, Z);
+    hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, mulv, eps, z, klrow, B, Z);
     }
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
-int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz, const float* gscale,
+int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
+                 const float* gscale,
                  const float* denoms, float* dmulv, int B, int Z) {
     if (B == 0) return 0;
     { ProfScope prof(s, KC_HEAD, 0);
-    hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, s, mulv, eps, dz, gscale, denoms, dmulv, B, Z);
+    hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, s, mulv, eps, dz0, dz1, dz2, gscale, denoms, dmulv, B, Z);
     }
     PSVAE_LAUNCH_CHECK();
     return 0;
@@ -246,10 +267,17 @@ int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const 
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
+int make_gscale(hipStream_t s, const float* g6, const float* w3, float* out4) {
+    ProfScope prof(s, KC_HEAD, 0);
+    hipLaunchKernelGGL(make_gscale_kernel, dim3(1), dim3(64), 0, s, g6, w3 ? w3[0] : 0.f, w3 ? w3[1] : 0.f, w3 ? w3[2] : 0.f, out4);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
 int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* piece_row, int rows_p,
-                    const float* edge_row, int S, const float* klrow, const float* denoms, float* losses) {
+                    const float* edge_row, int S, const float* klrow, const float* denoms, const float* w3, float* losses) {
     { ProfScope prof(s, KC_HEAD, 0);
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(256), 0, s, mse_row, B, piece_row, rows_p, edge_row, S, klrow, denoms, losses);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(256), 0, s, mse_row, B, piece_row, rows_p, edge_row, S, klrow, denoms,
+                       w3 ? w3[0] : 0.f, w3 ? w3[1] : 0.f, w3 ? w3[2] : 0.f, losses);
     }
     PSVAE_LAUNCH_CHECK();
     return 0;

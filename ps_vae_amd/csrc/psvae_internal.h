@@ -117,7 +117,8 @@ int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_
 
 // ------------------------------------------------------------ heads / losses
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z);
-int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz, const float* gscale,
+int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
+                 const float* gscale,
                  const float* denoms, float* dmulv, int B, int Z);
 int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse);
@@ -128,7 +129,8 @@ int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float*
 int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const float* gscale, const float* denoms,
             float* dpred, int B, int P);
 int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* piece_row, int rows_p,
-                    const float* edge_row, int S, const float* klrow, const float* denoms, float* losses);
+                    const float* edge_row, int S, const float* klrow, const float* denoms, const float* w3, float* losses);
+int make_gscale(hipStream_t s, const float* g6, const float* w3, float* out4);
 int fill_zero(hipStream_t s, float* p, int64_t count);
 
 // ------------------------------------------------------------ GRU

@@ -9,6 +9,8 @@
 // encoder and the decoder-side encoder together (grid dimension = group).
 #include "psvae_internal.h"
 #include <string.h>
+#include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -45,10 +47,10 @@ struct WS {
     float *semb, *gi, *h0, *hseq, *hprev, *gates, *logits, *rowloss_p, *lse_p;
     float *pin, *s1, *s2, *s3, *slog, *rowloss_e, *lse_e, *q1, *q2, *pred, *mse_row, *losses;
     // backward
-    float *dpred, *dq2, *dq1, *dz, *dhseq, *dgi, *dgh, *dh0, *dsemb, *ds3, *ds2, *ds1, *dpin;
+    float *dpred, *dq2, *dq1, *dz, *dz_piece, *dz_pair, *gscale, *dhseq, *dgi, *dgh, *dh0, *dsemb, *ds3, *ds2, *ds1, *dpin;
     float *dmulv, *dcond, *dpooled, *GE, *GD, *G0, *DHE, *DHD, *DAE, *DAD, *dX0, *etab_part;
     float *tg_part; size_t tg_part_floats;
-    float *scratch; size_t scratch_floats;
+    float *scratch, *scratch1, *scratch2; size_t scratch_floats;
     size_t total_floats;
 };
 
@@ -81,7 +83,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         {"edge_lse", &WS::lse_e, S}, {"pred_h1", &WS::q1, B * s.Hp}, {"pred_h2", &WS::q2, B * s.Hp},
         {"pred", &WS::pred, B * s.ldpred}, {"mse_row", &WS::mse_row, B}, {"losses", &WS::losses, 8},
         {"d_pred", &WS::dpred, B * s.ldpred}, {"d_pred_h2", &WS::dq2, B * s.Hp}, {"d_pred_h1", &WS::dq1, B * s.Hp},
-        {"d_z", &WS::dz, B * s.Z}, {"d_rnn_out", &WS::dhseq, BT * s.R}, {"d_gi", &WS::dgi, BT * 3 * s.R},
+        {"d_z", &WS::dz, B * s.Z}, {"d_z_piece", &WS::dz_piece, B * s.Z}, {"d_z_pair", &WS::dz_pair, B * s.Z}, {"gscale", &WS::gscale, 8}, {"d_rnn_out", &WS::dhseq, BT * s.R}, {"d_gi", &WS::dgi, BT * 3 * s.R},
         {"d_gh", &WS::dgh, BT * 3 * s.R}, {"d_h0", &WS::dh0, B * s.R}, {"d_seq_emb", &WS::dsemb, BT * s.Dp},
         {"d_pair_h3", &WS::ds3, S * s.P}, {"d_pair_h2", &WS::ds2, S * s.P2}, {"d_pair_h1", &WS::ds1, S * s.P2},
         {"d_pair_in", &WS::dpin, S * s.P}, {"d_mulv", &WS::dmulv, B * 2 * s.Z}, {"d_cond", &WS::dcond, B * s.G},
@@ -91,7 +93,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         {"enc_dagg", &WS::DAE, n * s.te * H}, {"dec_dagg", &WS::DAD, n * s.td * H},
         {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * tmax * chunks * 4 * H},
         {"table_grad_part", &WS::tg_part, tg_part},
-        {"scratch", &WS::scratch, scratch},
+        {"scratch", &WS::scratch, scratch}, {"scratch1", &WS::scratch1, scratch}, {"scratch2", &WS::scratch2, scratch},
     };
     size_t off = 0;
     for (const Field& e : f) {
@@ -202,19 +204,52 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
         }
         PSVAE_TRY(gine_agg_bwd(st, ag, ng, H, ldx, l > 0 ? H : 2 * H, t * H, b.node_graph, n, H));
     }
-    for (int q = 0; q < ng; ++q) {  // shared weights: sum over the t applications
-        PSVAE_TRY(linear_bwd_w(st, k[q].Gr + nH, H, (int64_t)nH, k[q].Hid, H, (int64_t)nH, t, k[q].g_w2, k[q].g_b2, n, H, H,
-                               w.scratch, w.scratch_floats));
-        PSVAE_TRY(linear_bwd_w(st, k[q].DH, H, (int64_t)nH, k[q].A, H, (int64_t)nH, t, k[q].g_w1, k[q].g_b1, n, H, H,
-                               w.scratch, w.scratch_floats));
-    }
+    return 0;
+}
+
+// edge_trans gradients of 1 or 2 stacks with the same t (after stacks_backward)
+int stacks_edge_grads(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng, int slot0) {
+    const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
+    const size_t nH = (size_t)n * H;
     EtabGroup eg[2];
     const int chunks = etab_chunks(n);
     const int tmax = s.te > s.td ? s.te : s.td;
     for (int q = 0; q < ng; ++q)
         eg[q] = EtabGroup{k[q].DA, (int64_t)nH, k[q].X, (int64_t)H, k[q].rowptr, k[q].col, k[q].etype, k[q].edge_w, k[q].edge_b,
-                          k[q].g_edge_w, k[q].g_edge_b, w.etab_part + (size_t)(g0_slot0 + q) * tmax * chunks * 4 * H};
-    PSVAE_TRY(gine_etab_grad(st, eg, ng, t, H, ldx, n, H, chunks));
+                          k[q].g_edge_w, k[q].g_edge_b, w.etab_part + (size_t)(slot0 + q) * tmax * chunks * 4 * H};
+    return gine_etab_grad(st, eg, ng, t, H, ldx, n, H, chunks);
+}
+
+// Side streams ("lanes") for the branches of the step that do not depend on each other: the
+// piece/GRU branch and the property head run beside the link scorer, and weight-gradient
+// products run beside the input-gradient chain.  Fork and join are event waits on the
+// caller's stream, so from outside the call still behaves like work on that one stream.
+// Set PSVAE_STREAMS=0 to run everything on the caller's stream.
+struct Lanes { hipStream_t s1, s2; hipEvent_t ev[12]; };
+Lanes* get_lanes() {
+    static std::mutex mu;
+    static Lanes* per_device[64] = {};
+    static int disabled = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (disabled < 0) { const char* e = getenv("PSVAE_STREAMS"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!per_device[dev]) {
+        Lanes* l = new Lanes();
+        bool ok = hipStreamCreateWithFlags(&l->s1, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&l->s2, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 12; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { delete l; disabled = 1; return nullptr; }
+        per_device[dev] = l;
+    }
+    return per_device[dev];
+}
+// `to` waits for everything enqueued so far on `from`
+int hand_over(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+    if (from == to) return 0;
+    if (hipEventRecord(ev, from) != hipSuccess) return (int)hipGetLastError();
+    if (hipStreamWaitEvent(to, ev, 0) != hipSuccess) return (int)hipGetLastError();
     return 0;
 }
 
@@ -266,7 +301,8 @@ extern "C" int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_ba
 }
 
 extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
-                                  void* workspace, size_t workspace_bytes, float* losses, void* stream) {
+                                  void* workspace, size_t workspace_bytes, const float* loss_weights, float* losses,
+                                  void* stream) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !losses) return PSVAE_E_NULL;
     if (!aligned16(workspace)) return PSVAE_E_ALIGN;
@@ -275,36 +311,45 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     WS w;
     if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    Lanes* L = get_lanes();
+    hipStream_t s1 = L ? L->s1 : st, s2 = L ? L->s2 : st;
+    const size_t scf = w.scratch_floats;
 
+    // lane 1 starts with the part of the piece branch that needs no latent: token embeddings and
+    // the GRU input products for all steps (src/modules/vae_piece_decoder.py:82,87-89)
+    if (L) PSVAE_TRY(hand_over(st, s1, L->ev[0]));
+    PSVAE_TRY(rows_gather(s1, b.pieces, 0, s.T, s.L, p.piece_emb, s.Dp, w.semb, s.BT));
+    PSVAE_TRY(linear_fwd(s1, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch1, scf));
+    // main: encoder and decoder-side GINE stacks, pooling, latent
     PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true));
     PSVAE_TRY(vae_head_fwd(st, w.mulv, b.eps, w.z, w.klrow, s.B, s.Z));
-    // property head (src/modules/predictor.py:19-21) + squared error rows
-    PSVAE_TRY(linear_fwd(st, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch, w.scratch_floats));
-    PSVAE_TRY(linear_fwd(st, w.q1, s.Hp, p.pred_w1, p.pred_b1, w.q2, s.Hp, s.B, s.Hp, s.Hp, 1, w.scratch, w.scratch_floats));
-    PSVAE_TRY(linear_fwd(st, w.q2, s.Hp, p.pred_wo, p.pred_bo, w.pred, s.ldpred, s.B, s.NP, s.Hp, 0, w.scratch, w.scratch_floats));
-    PSVAE_TRY(mse_fwd(st, w.pred, s.ldpred, b.props, w.mse_row, s.B, s.NP));
-    // piece branch (src/modules/vae_piece_decoder.py:81-90)
-    PSVAE_TRY(rows_gather(st, b.pieces, 0, s.T, s.L, p.piece_emb, s.Dp, w.semb, s.BT));
-    PSVAE_TRY(linear_fwd(st, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch, w.scratch_floats));
-    PSVAE_TRY(linear_fwd(st, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, 0, w.scratch, w.scratch_floats));
-    PSVAE_TRY(gru_fwd(st, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R));
-    PSVAE_TRY(linear_fwd(st, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch, w.scratch_floats));
-    PSVAE_TRY(softmax_ce_fwd(st, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
-    // link scorer (src/modules/vae_piece_decoder.py:97-110)
+    if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[1])); PSVAE_TRY(hand_over(st, s2, L->ev[2])); }
+    // lane 1: GRU + vocabulary logits + piece loss rows
+    PSVAE_TRY(linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, 0, w.scratch1, scf));
+    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R));
+    PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
+    PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
+    // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
+    PSVAE_TRY(linear_fwd(s2, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch2, scf));
+    PSVAE_TRY(linear_fwd(s2, w.q1, s.Hp, p.pred_w1, p.pred_b1, w.q2, s.Hp, s.B, s.Hp, s.Hp, 1, w.scratch2, scf));
+    PSVAE_TRY(linear_fwd(s2, w.q2, s.Hp, p.pred_wo, p.pred_bo, w.pred, s.ldpred, s.B, s.NP, s.Hp, 0, w.scratch2, scf));
+    PSVAE_TRY(mse_fwd(s2, w.pred, s.ldpred, b.props, w.mse_row, s.B, s.NP));
+    // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
     PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
-    PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, w.scratch_floats));
-    PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, w.scratch_floats));
-    PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, w.scratch_floats));
-    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, w.scratch_floats));
+    PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
     PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
-    PSVAE_TRY(losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, w.losses));
-    if (hipMemcpyAsync(losses, w.losses, 5 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+    if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[3])); PSVAE_TRY(hand_over(s2, st, L->ev[4])); }
+    PSVAE_TRY(losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, w.losses));
+    if (hipMemcpyAsync(losses, w.losses, 6 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
     return 0;
 }
 
 extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
-                                   void* workspace, size_t workspace_bytes, const float* loss_grads,
-                                   const psvae_params* grads, void* stream) {
+                                   void* workspace, size_t workspace_bytes, const float* loss_weights,
+                                   const float* loss_grads, const psvae_params* grads, void* stream) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !loss_grads || !grads) return PSVAE_E_NULL;
     const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_params& g = *grads; const psvae_batch& b = *batch;
@@ -312,42 +357,55 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     WS w;
     if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const float* gs = loss_grads;  // [pred, piece, edge, kl]
-    float* sc = w.scratch; const size_t scf = w.scratch_floats;
-
-    // --- property head
-    PSVAE_TRY(mse_bwd(st, w.pred, s.ldpred, b.props, gs, b.denoms, w.dpred, s.B, s.NP));
-    PSVAE_TRY(linear_bwd_w(st, w.dpred, s.ldpred, 0, w.q2, s.Hp, 0, 1, g.pred_wo, g.pred_bo, s.B, s.NP, s.Hp, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.dpred, s.ldpred, p.pred_wo, w.dq2, s.Hp, s.B, s.NP, s.Hp, w.q2, s.Hp, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.dq2, s.Hp, 0, w.q1, s.Hp, 0, 1, g.pred_w1, g.pred_b1, s.B, s.Hp, s.Hp, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.dq2, s.Hp, p.pred_w1, w.dq1, s.Hp, s.B, s.Hp, s.Hp, w.q1, s.Hp, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.dq1, s.Hp, 0, w.z, s.Z, 0, 1, g.pred_w0, g.pred_b0, s.B, s.Hp, s.Z, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.dq1, s.Hp, p.pred_w0, w.dz, s.Z, s.B, s.Hp, s.Z, nullptr, 0, 0));
-    // --- piece branch
-    PSVAE_TRY(softmax_ce_bwd(st, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.logits, s.ldl, 0, w.hseq, s.R, 0, 1, g.vocab_w, g.vocab_b, s.BT, s.V2, s.R, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
-    PSVAE_TRY(gru_bwd(st, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R));
-    PSVAE_TRY(linear_bwd_w(st, w.dgh, 3 * s.R, 0, w.hprev, s.R, 0, 1, g.gru_whh, g.gru_bhh, s.BT, 3 * s.R, s.R, sc, scf));
-    PSVAE_TRY(linear_bwd_w(st, w.dgi, 3 * s.R, 0, w.semb, s.Dp, 0, 1, g.gru_wih, g.gru_bih, s.BT, 3 * s.R, s.Dp, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.dh0, s.R, 0, w.z, s.Z, 0, 1, g.l2h_w, g.l2h_b, s.B, s.R, s.Z, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.dh0, s.R, p.l2h_w, w.dz, s.Z, s.B, s.R, s.Z, nullptr, 0, 1));
-    // --- link scorer
-    PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
-    PSVAE_TRY(linear_bwd_w(st, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.ds3, s.P, p.sc_w2, w.ds2, s.P2, s.S, s.P, s.P2, w.s2, s.P2, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.ds2, s.P2, 0, w.s1, s.P2, 0, 1, g.sc_w1, g.sc_b1, s.S, s.P2, s.P2, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.ds2, s.P2, p.sc_w1, w.ds1, s.P2, s.S, s.P2, s.P2, w.s1, s.P2, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.ds1, s.P2, p.sc_w0, w.dpin, s.P, s.S, s.P2, s.P, nullptr, 0, 0));
+    Lanes* L = get_lanes();
+    hipStream_t s1 = L ? L->s1 : st, s2 = L ? L->s2 : st;
+    const size_t scf = w.scratch_floats;
+    float *sc = w.scratch, *sc1 = w.scratch1, *sc2 = w.scratch2;
     const size_t nH = (size_t)s.n * s.H;
+
+    PSVAE_TRY(make_gscale(st, loss_grads, loss_weights, w.gscale));
+    const float* gs = w.gscale;  // upstream gradients of [pred, piece, edge, kl]
+    if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[0])); PSVAE_TRY(hand_over(st, s2, L->ev[1])); }
+    // --- lane 1: piece branch (cross-entropy, to_vocab, GRU, latent_to_rnn_hidden)
+    PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
+    PSVAE_TRY(linear_bwd_x(s1, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
+    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R));
+    PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
+    PSVAE_TRY(linear_bwd_x(s1, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
+    if (L && hipEventRecord(L->ev[2], s1) != hipSuccess) return (int)hipGetLastError();   // dz_piece, dsemb ready
+    PSVAE_TRY(linear_bwd_w(s1, w.logits, s.ldl, 0, w.hseq, s.R, 0, 1, g.vocab_w, g.vocab_b, s.BT, s.V2, s.R, sc1, scf));
+    PSVAE_TRY(linear_bwd_w(s1, w.dgh, 3 * s.R, 0, w.hprev, s.R, 0, 1, g.gru_whh, g.gru_bhh, s.BT, 3 * s.R, s.R, sc1, scf));
+    PSVAE_TRY(linear_bwd_w(s1, w.dgi, 3 * s.R, 0, w.semb, s.Dp, 0, 1, g.gru_wih, g.gru_bih, s.BT, 3 * s.R, s.Dp, sc1, scf));
+    PSVAE_TRY(linear_bwd_w(s1, w.dh0, s.R, 0, w.z, s.Z, 0, 1, g.l2h_w, g.l2h_b, s.B, s.R, s.Z, sc1, scf));
+    // --- lane 2: property head
+    PSVAE_TRY(mse_bwd(s2, w.pred, s.ldpred, b.props, gs, b.denoms, w.dpred, s.B, s.NP));
+    PSVAE_TRY(linear_bwd_x(s2, w.dpred, s.ldpred, p.pred_wo, w.dq2, s.Hp, s.B, s.NP, s.Hp, w.q2, s.Hp, 0));
+    PSVAE_TRY(linear_bwd_x(s2, w.dq2, s.Hp, p.pred_w1, w.dq1, s.Hp, s.B, s.Hp, s.Hp, w.q1, s.Hp, 0));
+    PSVAE_TRY(linear_bwd_x(s2, w.dq1, s.Hp, p.pred_w0, w.dz, s.Z, s.B, s.Hp, s.Z, nullptr, 0, 0));
+    if (L && hipEventRecord(L->ev[3], s2) != hipSuccess) return (int)hipGetLastError();   // dz (property head part) ready
+    PSVAE_TRY(linear_bwd_w(s2, w.dpred, s.ldpred, 0, w.q2, s.Hp, 0, 1, g.pred_wo, g.pred_bo, s.B, s.NP, s.Hp, sc2, scf));
+    PSVAE_TRY(linear_bwd_w(s2, w.dq2, s.Hp, 0, w.q1, s.Hp, 0, 1, g.pred_w1, g.pred_b1, s.B, s.Hp, s.Hp, sc2, scf));
+    PSVAE_TRY(linear_bwd_w(s2, w.dq1, s.Hp, 0, w.z, s.Z, 0, 1, g.pred_w0, g.pred_b0, s.B, s.Hp, s.Z, sc2, scf));
+    // --- main: link scorer input-gradient chain; its weight gradients follow on lane 2
+    PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
+    if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
+    PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
+    if (L) PSVAE_TRY(hand_over(st, s2, L->ev[5]));
+    PSVAE_TRY(linear_bwd_w(s2, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc2, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.ds3, s.P, p.sc_w2, w.ds2, s.P2, s.S, s.P, s.P2, w.s2, s.P2, 0));
+    if (L) PSVAE_TRY(hand_over(st, s2, L->ev[6]));
+    PSVAE_TRY(linear_bwd_w(s2, w.ds2, s.P2, 0, w.s1, s.P2, 0, 1, g.sc_w1, g.sc_b1, s.S, s.P2, s.P2, sc2, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.ds2, s.P2, p.sc_w1, w.ds1, s.P2, s.S, s.P2, s.P2, w.s1, s.P2, 0));
+    if (L) PSVAE_TRY(hand_over(st, s2, L->ev[7]));
+    PSVAE_TRY(linear_bwd_w(s2, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc2, scf));
+    PSVAE_TRY(linear_bwd_x(st, w.ds1, s.P2, p.sc_w0, w.dpin, s.P, s.S, s.P2, s.P, nullptr, 0, 0));
     PSVAE_TRY(pair_scatter(st, w.dpin, s.P, b.pair_by_src_ptr, b.pair_by_src_idx, b.pair_by_dst_ptr, b.pair_by_dst_idx,
-                           b.pair_graph_off, w.GD + (size_t)s.td * nH, s.H, w.dz, 1, s.n, s.B, s.H, s.Z));
-    // --- latent head and encoder.linear
-    PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz, gs, b.denoms, w.dmulv, s.B, s.Z));
+                           b.pair_graph_off, w.GD + (size_t)s.td * nH, s.H, w.dz_pair, 0, s.n, s.B, s.H, s.Z));
+    // --- latent head and encoder.linear: needs the three parts of dL/dz
+    if (L && (hipStreamWaitEvent(st, L->ev[2], 0) != hipSuccess || hipStreamWaitEvent(st, L->ev[3], 0) != hipSuccess))
+        return (int)hipGetLastError();
+    PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz, w.dz_piece, w.dz_pair, gs, b.denoms, w.dmulv, s.B, s.Z));
     const bool head_adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z &&
                                g.lvar_w == g.mean_w + (size_t)s.Z * s.G && g.lvar_b == g.mean_b + s.Z;
     if (head_adjacent) {
@@ -360,8 +418,8 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
         PSVAE_TRY(linear_bwd_x(st, w.dmulv + s.Z, 2 * s.Z, p.lvar_w, w.dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 1));
     }
     const int TH = s.te * s.H;
-    PSVAE_TRY(linear_bwd_w(st, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc, scf));
     PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
+    PSVAE_TRY(linear_bwd_w(st, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc, scf));
     // --- GINE stacks: dL/dx_te of the encoder is the broadcast of the last pooled slice
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
     {
@@ -376,17 +434,34 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0));
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1));
     }
+    // weight gradients of the shared GINE MLPs (sum over the t applications): encoder on lane 1,
+    // decoder-side encoder on lane 2, beside node_trans / edge_trans / embedding tables on main
+    if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[8])); PSVAE_TRY(hand_over(st, s2, L->ev[9])); }
+    for (int q = 0; q < 2; ++q) {
+        hipStream_t sq = q == 0 ? s1 : s2;
+        float* scq = q == 0 ? sc1 : sc2;
+        PSVAE_TRY(linear_bwd_w(sq, k[q].Gr + nH, s.H, (int64_t)nH, k[q].Hid, s.H, (int64_t)nH, k[q].t, k[q].g_w2, k[q].g_b2,
+                               s.n, s.H, s.H, scq, scf));
+        PSVAE_TRY(linear_bwd_w(sq, k[q].DH, s.H, (int64_t)nH, k[q].A, s.H, (int64_t)nH, k[q].t, k[q].g_w1, k[q].g_b1,
+                               s.n, s.H, s.H, scq, scf));
+    }
+    if (s.te == s.td) {
+        PSVAE_TRY(stacks_edge_grads(st, s, w, k, 2, 0));
+    } else {
+        PSVAE_TRY(stacks_edge_grads(st, s, w, &k[0], 1, 0));
+        PSVAE_TRY(stacks_edge_grads(st, s, w, &k[1], 1, 1));
+    }
     // --- node_trans of both stacks from G0 = [dL/dx0_enc | dL/dx0_dec]  ([n, 2H])
     const bool node_adjacent = p.dec_node_w == p.enc_node_w + (size_t)s.H * s.Din && g.dec_node_w == g.enc_node_w + (size_t)s.H * s.Din &&
                                g.dec_node_b == g.enc_node_b + s.H;
     if (node_adjacent) {
-        PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, 2 * s.H, s.Din, sc, scf));
         PSVAE_TRY(linear_bwd_x(st, w.G0, 2 * s.H, p.enc_node_w, w.dX0, s.Din, s.n, 2 * s.H, s.Din, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, 2 * s.H, s.Din, sc, scf));
     } else {
-        PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, s.H, s.Din, sc, scf));
-        PSVAE_TRY(linear_bwd_w(st, w.G0 + s.H, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.dec_node_w, g.dec_node_b, s.n, s.H, s.Din, sc, scf));
         PSVAE_TRY(linear_bwd_x(st, w.G0, 2 * s.H, p.enc_node_w, w.dX0, s.Din, s.n, s.H, s.Din, nullptr, 0, 0));
         PSVAE_TRY(linear_bwd_x(st, w.G0 + s.H, 2 * s.H, p.dec_node_w, w.dX0, s.Din, s.n, s.H, s.Din, nullptr, 0, 1));
+        PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, s.H, s.Din, sc, scf));
+        PSVAE_TRY(linear_bwd_w(st, w.G0 + s.H, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.dec_node_w, g.dec_node_b, s.n, s.H, s.Din, sc, scf));
     }
     // --- embedding tables (piece table also receives the GRU-input gradient)
     const TableGradDesc tg[3] = {
@@ -395,6 +470,7 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
          b.seq_rows_ptr, b.seq_rows_idx, w.dsemb, s.Dp, 0},
         {g.pos_emb, d.max_pos, s.Dq, b.pos_rows_ptr, b.pos_rows_idx, w.dX0, s.Din, s.Da + s.Dp, nullptr, nullptr, nullptr, 0, 0}};
     PSVAE_TRY(table_grads(st, tg, 3, w.tg_part, w.tg_part_floats));
+    if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[10])); PSVAE_TRY(hand_over(s2, st, L->ev[11])); }
     return 0;
 }
 

@@ -50,7 +50,7 @@ UNTRAINED = ['decoder.graph_embedding.linear.weight', 'decoder.graph_embedding.l
 
 class _StepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, trigger, model, nb, eps):
+    def forward(ctx, trigger, model, nb, eps, weights):
         L = _lib.lib()
         dims, params = model._dims, model._params_struct
         bs = nb.struct(eps)
@@ -59,11 +59,12 @@ class _StepFn(torch.autograd.Function):
             raise RuntimeError('psvae_workspace_bytes rejected the model/batch sizes (hidden, latent and rnn sizes '
                                'must be multiples of 4; 4 bond types)')
         ws = torch.empty(nbytes, dtype=torch.uint8, device=eps.device)
-        losses = torch.empty(5, dtype=torch.float32, device=eps.device)
+        losses = torch.empty(6, dtype=torch.float32, device=eps.device)
         stream = torch.cuda.current_stream().cuda_stream
+        w3 = (C.c_float * 3)(*weights)
         _lib.check(L.psvae_step_forward(C.byref(dims), C.byref(params), C.byref(bs), ws.data_ptr(), nbytes,
-                                        losses.data_ptr(), stream), 'psvae_step_forward')
-        ctx.model, ctx.nb, ctx.eps, ctx.ws, ctx.nbytes = model, nb, eps, ws, nbytes
+                                        C.byref(w3), losses.data_ptr(), stream), 'psvae_step_forward')
+        ctx.model, ctx.nb, ctx.eps, ctx.ws, ctx.nbytes, ctx.w3 = model, nb, eps, ws, nbytes, w3
         model._last_ws = (ws, nb)
         return losses
 
@@ -71,17 +72,17 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, g):
         L = _lib.lib()
         model, nb = ctx.model, ctx.nb
-        # upstream gradients of (pred, piece, edge, kl); rec = piece + edge feeds both
-        gs = torch.stack([g[0], g[2] + g[1], g[3] + g[1], g[4]]).contiguous()
+        g = g.contiguous()   # upstream gradients of (pred, rec, piece, edge, kl, total)
         grads_struct, fresh = model._grad_target()
         bs = nb.struct(ctx.eps)
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(L.psvae_step_backward(C.byref(model._dims), C.byref(model._params_struct), C.byref(bs),
-                                         ctx.ws.data_ptr(), ctx.nbytes, gs.data_ptr(), C.byref(grads_struct), stream),
+                                         ctx.ws.data_ptr(), ctx.nbytes, C.byref(ctx.w3), g.data_ptr(),
+                                         C.byref(grads_struct), stream),
                    'psvae_step_backward')
         model._grad_written(fresh)
         ctx.ws = None
-        return g.new_zeros(()), None, None, None
+        return g.new_zeros(()), None, None, None, None
 
 
 class PSVAEModel(nn.Module):
@@ -221,7 +222,9 @@ class PSVAEModel(nn.Module):
         if eps is None:
             eps = torch.randn(B, self._dims.latent, dtype=torch.float32, device=self._flat.device)
         eps = eps.to(self._flat.device, torch.float32).contiguous()
-        out = _StepFn.apply(self._trigger, self, nb, eps)
+        alpha = float(self.config['alpha'])
+        out = _StepFn.apply(self._trigger, self, nb, eps, (1.0 - alpha, alpha, float(self.cal_beta())))
+        self._last_total = out[5]
         pred_loss, losses = out[0], (out[1], out[2], out[3], out[4])
         if return_accu:
             return pred_loss, (losses, self._accuracies(nb))
@@ -269,8 +272,10 @@ class PSVAEModel(nn.Module):
         return alpha * rec_loss + (1 - alpha) * pred_loss + self.cal_beta() * kl_loss
 
     def training_step(self, batch, batch_idx=0, eps=None):
-        pred_loss, rec_losses = self.forward(batch, eps=eps)
-        return self.weighted_loss(pred_loss, rec_losses[0], rec_losses[-1])
+        """`ps_vae_model.py:76-88`: forward + weighted loss.  The weighted sum is formed inside the
+        fused step (same value as `weighted_loss(pred, rec, kl)` at the current `global_step`)."""
+        self.forward(batch, eps=eps)
+        return self._last_total
 
     def configure_optimizers(self):
         from .optim import FusedClipAdam

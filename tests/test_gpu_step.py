@@ -216,3 +216,26 @@ def test_module_level_encoder_matches_oracle():
     q = torch.relu(torch.nn.functional.linear(q, sd['predictor.mlp.2.weight'], sd['predictor.mlp.2.bias']))
     want = torch.nn.functional.linear(q, sd['predictor.output.weight'], sd['predictor.output.bias'])
     check_close(model.predictor(z.cuda()), want, 'predictor')
+
+
+def test_training_step_total_equals_weighted_loss():
+    """`training_step` forms alpha*rec + (1-alpha)*pred + beta*kl inside the fused step; value and
+    gradients must equal the torch-side `weighted_loss` route, with and without the side streams."""
+    from ps_vae_amd import synth
+    d, V, B = O.default_dims(300), 300, 24
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(55, 'zinc', V, B)
+    _, batch = collate_both(mols, tok, V, 4)
+    eps = torch.randn(B, d['latent'], generator=torch.Generator().manual_seed(2))
+    model.global_step = 2500   # beta = 0.006
+    model.zero_grad()
+    pred, (rec, _, _, kl) = model(batch, eps=eps)
+    total_a = model.weighted_loss(pred, rec, kl)
+    total_a.backward()
+    g_a = model.flat_buffers()[1].clone()
+    model.zero_grad()
+    total_b = model.training_step(batch, eps=eps)
+    total_b.backward()
+    g_b = model.flat_buffers()[1].clone()
+    assert abs(float(total_a.detach()) - float(total_b.detach())) <= 1e-6 * abs(float(total_a.detach()))
+    check_close(g_b, g_a, 'gradients via fused total', rtol=1e-5, atol_scale=1e-6)
