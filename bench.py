@@ -45,11 +45,19 @@ def make_batches(tok, vocab, shape, batch_size, count, seed):
     return out, t_collate / count
 
 
-def cpu_baseline(cpu_batch, vocab, budget_s=12.0, max_steps=8):
-    """The CPU oracle's training step (the reference's op sequence in plain PyTorch) on the host cores."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _time_oracle(cpu_batch, vocab, budget_s, max_steps):
     from oracle import psvae_oracle as O
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     d = O.default_dims(vocab)
     tr = O.Trainer(O.make_params(d), d)
     B = cpu_batch['x'].shape[0]
@@ -59,10 +67,21 @@ def cpu_baseline(cpu_batch, vocab, budget_s=12.0, max_steps=8):
     while n < max_steps and (time.perf_counter() - t0 < budget_s or n == 0):
         tr.step(cpu_batch, eps)
         n += 1
-    dt = time.perf_counter() - t0
-    return {'value': B * n / dt, 'unit': 'molecules/s', 'cores': threads, 'kind': 'port',
+    return B, n, time.perf_counter() - t0
+
+
+def cpu_baseline(cpu_batch, qm9_batch, vocab, budget_s=12.0, max_steps=8):
+    """The CPU oracle's training step (the reference's op sequence in plain PyTorch) on the host cores:
+    the benchmark's own batch, and the reference's CPU-runnable case (QM9-shape, 32 graphs) beside it."""
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    B, n, dt = _time_oracle(cpu_batch, vocab, budget_s, max_steps)
+    Bq, nq, dtq = _time_oracle(qm9_batch, vocab, 4.0, 30)
+    return {'value': B * n / dt, 'unit': 'molecules/s', 'cores': threads, 'kind': 'port', 'cpu_model': _cpu_model(),
             'sample': f'{n} training steps of the CPU oracle on one batch of {B} synthetic ZINC-shape graphs '
-                      f'({dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU)'}
+                      f'({dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU)',
+            'qm9_b32': {'value': Bq * nq / dtq, 'unit': 'molecules/s',
+                        'sample': f'{nq} steps on one batch of {Bq} QM9-shape graphs ({dtq / nq * 1e3:.1f} ms/step)'}}
 
 
 def main():
@@ -183,7 +202,8 @@ def main():
         'kernel_classes': table,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cpu_batches[0], args.vocab)
+        qm9, _ = make_batches(tok, args.vocab, 'qm9', 32, 1, seed=7)
+        out['cpu_baseline'] = cpu_baseline(cpu_batches[0], qm9[0], args.vocab)
     print(json.dumps(out))
 
 

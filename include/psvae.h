@@ -13,7 +13,9 @@
  *    Float tensors are fp32, index tensors int32, row-major, contiguous unless a
  *    leading dimension ("ld", in elements) is passed.
  *  - The caller owns every buffer, including the workspace; the library
- *    allocates no device memory and keeps no state between calls.
+ *    allocates no device memory.  Its only state is, per device, two side
+ *    streams and a set of events created on the first step call (see
+ *    psvae_step_forward), so step calls on one device must not overlap.
  *  - Work is enqueued on the hipStream_t passed as `stream` (a void* here so the
  *    header needs no HIP include); no entry point synchronises the device.
  *  - Return value: 0 = success; negative = PSVAE_E_* argument error detected on
