@@ -208,11 +208,18 @@ int psvae_gine_edge_grad(const float* da, int ldda, const float* x, int ldx, con
 /* graph sum-pool: pooled[b] = sum of rows graph_off[b]..graph_off[b+1]. src/modules/encoder.py:64-67 */
 int psvae_segment_pool_forward(const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
                                int B, int width, void* stream);
-/* nn.GRU(batch_first, 1 layer) over T steps given gi = x W_ih^T + b_ih. src/modules/vae_piece_decoder.py:29,89 */
+/* nn.GRU(batch_first, 1 layer) over T steps given gi = x W_ih^T + b_ih. src/modules/vae_piece_decoder.py:29,89
+ * `exchange`: device scratch of psvae_gru_exchange_bytes(B,T,R) bytes, 16-byte aligned, through which the
+ * workgroups that share a sequence tile hand each other the hidden state every step (multi-CU recurrence,
+ * 16 <= R <= 256).  NULL selects the single-CU kernels (one workgroup per 16 sequences).  Two calls that use
+ * the same exchange buffer must not overlap. */
+size_t psvae_gru_exchange_bytes(int B, int T, int R);
 int psvae_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-                      float* hprev, float* gates, int B, int T, int R, void* stream);
+                      float* hprev, float* gates, int B, int T, int R, void* exchange, size_t exchange_bytes,
+                      void* stream);
 int psvae_gru_backward(const float* dhseq, const float* hprev, const float* gates, const float* whh,
-                       float* dgi, float* dgh, float* dh0, int B, int T, int R, void* stream);
+                       float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exchange,
+                       size_t exchange_bytes, void* stream);
 /* CrossEntropyLoss rows (ignore_index): row_loss, lse per row. src/modules/vae_piece_decoder.py:53-54 */
 int psvae_softmax_ce_forward(const float* logits, int ld, const int32_t* target, int target_stride,
                              int target_offset, int rows_per_group, int rows, int classes, int ignore_index,

@@ -118,8 +118,10 @@ def lib():
     L.psvae_gine_edge_grad_scratch.argtypes = [C.c_int, C.c_int]
     L.psvae_gine_edge_grad.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     L.psvae_segment_pool_forward.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
-    L.psvae_gru_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
-    L.psvae_gru_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_gru_exchange_bytes.restype = C.c_size_t
+    L.psvae_gru_exchange_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.psvae_gru_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    L.psvae_gru_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.psvae_softmax_ce_forward.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.psvae_collate_pairs.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp, i64, P(i64), vp, P(i64),
                                       vp, vp, vp, vp, i64, P(i64)]
@@ -144,7 +146,7 @@ EXPORTS = (
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_gine_edge_grad', 'psvae_segment_pool_forward',
-    'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
+    'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
     'psvae_pack_bound', 'psvae_pack_batch', 'psvae_profile_enable', 'psvae_profile_num_classes',
     'psvae_profile_class_name', 'psvae_profile_collect')
 

@@ -91,18 +91,25 @@ extern "C" int psvae_segment_pool_forward(const float* x, int ldx, const int32_t
     return segment_pool_fwd((hipStream_t)stream, x, ldx, graph_off, pooled, ldp, B, width);
 }
 
+extern "C" size_t psvae_gru_exchange_bytes(int B, int T, int R) {
+    if (B < 0 || T < 0 || R < 4) return 0;
+    return gru_exchange_bytes(B, T, R);
+}
+
 extern "C" int psvae_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-                                 float* hprev, float* gates, int B, int T, int R, void* stream) {
+                                 float* hprev, float* gates, int B, int T, int R, void* exchange,
+                                 size_t exchange_bytes, void* stream) {
     if (!gi || !h0 || !whh || !bhh || !hseq || !hprev || !gates) return PSVAE_E_NULL;
     if (B < 0 || T < 0 || R < 4) return PSVAE_E_SHAPE;
-    return gru_fwd((hipStream_t)stream, gi, h0, whh, bhh, hseq, hprev, gates, B, T, R);
+    return gru_fwd((hipStream_t)stream, gi, h0, whh, bhh, hseq, hprev, gates, B, T, R, exchange, exchange_bytes);
 }
 
 extern "C" int psvae_gru_backward(const float* dhseq, const float* hprev, const float* gates, const float* whh,
-                                  float* dgi, float* dgh, float* dh0, int B, int T, int R, void* stream) {
+                                  float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exchange,
+                                  size_t exchange_bytes, void* stream) {
     if (!dhseq || !hprev || !gates || !whh || !dgi || !dgh || !dh0) return PSVAE_E_NULL;
     if (B < 0 || T < 0 || R < 4) return PSVAE_E_SHAPE;
-    return gru_bwd((hipStream_t)stream, dhseq, hprev, gates, whh, dgi, dgh, dh0, B, T, R);
+    return gru_bwd((hipStream_t)stream, dhseq, hprev, gates, whh, dgi, dgh, dh0, B, T, R, exchange, exchange_bytes);
 }
 
 extern "C" int psvae_softmax_ce_forward(const float* logits, int ld, const int32_t* target, int target_stride,

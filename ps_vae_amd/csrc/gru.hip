@@ -2,15 +2,27 @@
 // the reference builds it at src/modules/vae_piece_decoder.py:29 and runs it at :89).
 //
 // The input products gi = x W_ih^T + b_ih for all steps are one large GEMM done
-// elsewhere; what remains is the recurrence.  One workgroup keeps a tile of 16
-// sequences resident for all T steps: the hidden state lives in LDS, every wave
-// owns 16 hidden units and computes their three gate pre-activations with
-// v_mfma_f32_16x16x4_f32 (A = hidden tile from LDS, B = W_hh rows streamed from
-// L2), so r, z and n of one (sequence, unit) land in the same lane and the gate
-// math needs no exchange.  One barrier per time step.
+// elsewhere; what remains is the recurrence.  Two implementations:
 //
-// LDS image of a [16 x K] tile: element (row, k) at ((k>>2)*16 + row)*4 + (k&3),
-// i.e. one ds_read_b128 gives a lane 4 consecutive k of its row, conflict-free.
+//  * multi-CU ("coop"): the recurrence of 16 sequences is spread over R/16
+//    workgroups, one per 16 hidden units.  Each keeps its slice of W_hh in
+//    registers for the whole sequence, computes its units' gate pre-activations
+//    with v_mfma_f32_16x16x4_f32 (K split over the 4 waves, summed through LDS)
+//    and hands its 16x16 piece of the new hidden state to the other workgroups of
+//    the group through global memory as 8-byte {step tag, value} words written
+//    with agent-scope atomic stores; consumers re-read their MFMA fragments with
+//    agent-scope atomic loads until every tag carries the step they wait for, so
+//    no flag, fence or grid barrier is needed and the step costs one cross-CU
+//    hop.  Needs a caller-provided exchange buffer (zeroed here before each
+//    launch) and all workgroups of a group resident at once, which the launch
+//    guarantees by capping the grid at the CU count; every wait is bounded.
+//  * single-CU: one workgroup per 16 sequences with the hidden state in LDS,
+//    W_hh streamed from L2 every step.  Used when no exchange buffer is given or
+//    R is outside the coop kernels' register budget.
+//
+// LDS image of a [16 x K] tile (single-CU kernels): element (row, k) at
+// ((k>>2)*16 + row)*4 + (k&3), i.e. one ds_read_b128 gives a lane 4 consecutive k
+// of its row, conflict-free.
 #include "psvae_internal.h"
 
 namespace {
@@ -185,13 +197,277 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// multi-CU recurrence
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr unsigned long long SPIN_LIMIT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock
+constexpr int EXCH_HEADER_WORDS = 32;                            // 256 B: word 0 = give-up flag
+
+__device__ __forceinline__ unsigned long long granule(unsigned tag, float v) {
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// One wave re-reads its `count` (<= N, wave-uniform, >= 1) exchange words, `stride` words apart, until every
+// one carries `tag`.  Gives up (returns false) when another wave has given up or after SPIN_LIMIT_TICKS.
+template <int N>
+__device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, unsigned tag, float (&v)[N], gu32* giveup,
+                                      int lane) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int ii = i < count ? i : count - 1;     // surplus slots repeat the last word: no branch around a load
+            const unsigned long long x = __hip_atomic_load(first + ii * stride, RLX_AGENT);
+            v[i] = __uint_as_float((unsigned)x);
+            ok &= (unsigned)(x >> 32) == tag;
+        }
+        if (__all(ok)) return true;
+        if ((spins & 63u) == 0u) {
+            if (__hip_atomic_load(giveup, RLX_AGENT) != 0u) return false;
+            if (wall_clock64() - t0 > SPIN_LIMIT_TICKS) {
+                if (lane == 0) __hip_atomic_store(giveup, 1u, RLX_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// grid (hidden tiles, sequence-tile slots); block 256.  Thread (wave w, lane l) owns element
+// (row 4*(l>>4)+w, unit j0+(l&15)) of the tile for the gate arithmetic = register w of lane l in the MFMA
+// output layout, so the cross-wave K reduction reads LDS without bank conflicts.
+// Exchange buffer: [parity][sequence tile][k][16 rows] words; h_t carries tag t.
+template <int KSW>
+__global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
+                                                           const float* __restrict__ whh, const float* __restrict__ bhh,
+                                                           float* __restrict__ hseq, float* __restrict__ hprev,
+                                                           float* __restrict__ gates, unsigned long long* exch_,
+                                                           int B, int T, int R, int n_st) {
+    __shared__ float red[2][4][3][4][64];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16;
+    const int nks = R >> 2;
+    const int cnt = nks > wave ? (nks - wave + 3) >> 2 : 0;        // this wave's K-steps: ks = wave + 4 i
+    gu32* giveup = (gu32*)exch_;
+    gu64* exch = (gu64*)exch_ + EXCH_HEADER_WORDS;
+    const int ucol = min(j0 + j, R - 1);                           // B-operand column (columns >= R are discarded)
+    float wr[KSW], wz[KSW], wn[KSW];
+#pragma unroll
+    for (int i = 0; i < KSW; ++i) {
+        const int k = min(4 * (wave + 4 * i) + kq, R - 1);
+        const float* w = whh + (long long)ucol * R + k;
+        const bool ok = i < cnt;
+        const float a = w[0], b = w[(long long)R * R], c = w[2ll * R * R];
+        wr[i] = ok ? a : 0.f; wz[i] = ok ? b : 0.f; wn[i] = ok ? c : 0.f;
+    }
+    const int erow = 4 * kq + wave, eunit = j0 + j;
+    const bool uok = eunit < R;
+    const int euc = min(eunit, R - 1);
+    const float cr = bhh[euc], cz = bhh[R + euc], cn = bhh[2 * R + euc];
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    bool dead = false;
+    for (int st = blockIdx.y; st < n_st && !dead; st += gridDim.y) {
+        const int b0 = st * 16;
+        const int eb = b0 + erow, ebc = min(eb, B - 1);
+        const bool eok = uok && eb < B;
+        const int arow = min(b0 + j, B - 1);
+        const bool aok = b0 + j < B;
+        float hp = h0[(long long)ebc * R + euc];
+        if (!eok) hp = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float* g = gi + ((long long)ebc * T + t) * 3 * R + euc;
+            const float gir = g[0], giz = g[R], gin = g[2 * R];
+            float a[KSW];
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < KSW; ++i) {
+                    const int k = min(4 * (wave + 4 * i) + kq, R - 1);
+                    const float v = h0[(long long)arow * R + k];
+                    a[i] = aok ? v : 0.f;
+                }
+            } else if (cnt > 0) {
+                gu64* first = exch + ((long long)((t & 1) * n_st + st) * R + 4 * wave + kq) * 16 + j;
+                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)t, a, giveup, lane)) s_fail = 1;
+            }
+            floatx4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) {
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wr[i], ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wz[i], az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wn[i], an, 0, 0, 0);
+            }
+            float(*rd)[3][4][64] = red[t & 1];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                rd[wave][0][reg][lane] = ar[reg];
+                rd[wave][1][reg][lane] = az[reg];
+                rd[wave][2][reg][lane] = an[reg];
+            }
+            __syncthreads();
+            if (s_fail) { dead = true; break; }
+            const float ghr = rd[0][0][wave][lane] + rd[1][0][wave][lane] + rd[2][0][wave][lane] + rd[3][0][wave][lane];
+            const float ghz = rd[0][1][wave][lane] + rd[1][1][wave][lane] + rd[2][1][wave][lane] + rd[3][1][wave][lane];
+            const float ghn = rd[0][2][wave][lane] + rd[1][2][wave][lane] + rd[2][2][wave][lane] + rd[3][2][wave][lane] + cn;
+            const float r = sigmoidf_(gir + ghr + cr);
+            const float u = sigmoidf_(giz + ghz + cz);
+            const float c = tanhf(gin + r * ghn);
+            const float hn = eok ? (1.0f - u) * c + u * hp : 0.f;
+            if (uok && t + 1 < T)   // rows past the batch publish zeros: consumers sweep all 16 rows
+                __hip_atomic_store(exch + ((long long)(((t + 1) & 1) * n_st + st) * R + eunit) * 16 + erow,
+                                   granule((unsigned)(t + 1), hn), RLX_AGENT);
+            if (eok) {
+                const long long base = (long long)eb * T + t;
+                hseq[base * R + eunit] = hn;
+                hprev[base * R + eunit] = hp;
+                float* gs = gates + base * 4 * R;
+                gs[eunit] = r; gs[R + eunit] = u; gs[2 * R + eunit] = c; gs[3 * R + eunit] = ghn;
+            }
+            hp = hn;
+        }
+        __syncthreads();   // the next sequence tile starts over on red[0]
+    }
+}
+
+// Backward recurrence, same partition: a workgroup owns dL/dh of its 16 units.  Per step it turns that
+// into the three gate gradients, publishes them (tag = step count from the end), gathers the full
+// d(gh) row block [16 x 3R] and multiplies it with its 16 columns of W_hh.
+template <int KSW>
+__global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restrict__ dhseq, const float* __restrict__ hprev,
+                                                           const float* __restrict__ gates, const float* __restrict__ whh,
+                                                           float* __restrict__ dgi, float* __restrict__ dgh,
+                                                           float* __restrict__ dh0, unsigned long long* exch_,
+                                                           int B, int T, int R, int n_st) {
+    __shared__ float red[2][4][4][64];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16;
+    const int G = 3 * R, nks = G >> 2;
+    const int cnt = nks > wave ? (nks - wave + 3) >> 2 : 0;
+    gu32* giveup = (gu32*)exch_;
+    gu64* exch = (gu64*)exch_ + EXCH_HEADER_WORDS;
+    const int ucol = min(j0 + j, R - 1);
+    float wb[KSW];
+#pragma unroll
+    for (int i = 0; i < KSW; ++i) {
+        const int k = min(4 * (wave + 4 * i) + kq, G - 1);
+        const float v = whh[(long long)k * R + ucol];
+        wb[i] = i < cnt ? v : 0.f;
+    }
+    const int erow = 4 * kq + wave, eunit = j0 + j;
+    const bool uok = eunit < R;
+    const int euc = min(eunit, R - 1);
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    bool dead = false;
+    for (int st = blockIdx.y; st < n_st && !dead; st += gridDim.y) {
+        const int b0 = st * 16;
+        const int eb = b0 + erow, ebc = min(eb, B - 1);
+        const bool eok = uok && eb < B;
+        float dh = 0.f;
+        // operands of the step are fetched one step ahead (plain loads of the forward pass's outputs)
+        long long base = (long long)ebc * T + (T - 1);
+        float n_d = dhseq[base * R + euc], n_hp = hprev[base * R + euc];
+        float n_r = gates[base * 4 * R + euc], n_z = gates[base * 4 * R + R + euc];
+        float n_c = gates[base * 4 * R + 2 * R + euc], n_g = gates[base * 4 * R + 3 * R + euc];
+        for (int t = T - 1, sidx = 0; t >= 0; --t, ++sidx) {
+            const float d = eok ? dh + n_d : 0.f;
+            const float r = n_r, z = n_z, c = n_c, ghn = n_g, hp = n_hp;
+            const float dpc = d * (1.0f - z) * (1.0f - c * c);
+            const float dpu = d * (hp - c) * z * (1.0f - z);
+            const float dghn = dpc * r;
+            const float dpr = dpc * ghn * r * (1.0f - r);
+            gu64* slab = exch + (long long)((sidx & 1) * n_st + st) * G * 16;
+            if (uok) {
+                const unsigned tag = (unsigned)(sidx + 1);
+                __hip_atomic_store(slab + (long long)eunit * 16 + erow, granule(tag, dpr), RLX_AGENT);
+                __hip_atomic_store(slab + (long long)(R + eunit) * 16 + erow, granule(tag, dpu), RLX_AGENT);
+                __hip_atomic_store(slab + (long long)(2 * R + eunit) * 16 + erow, granule(tag, dghn), RLX_AGENT);
+            }
+            if (eok) {
+                const long long bs = (long long)eb * T + t;
+                float* o1 = dgi + bs * G;
+                float* o2 = dgh + bs * G;
+                o1[eunit] = dpr; o1[R + eunit] = dpu; o1[2 * R + eunit] = dpc;
+                o2[eunit] = dpr; o2[R + eunit] = dpu; o2[2 * R + eunit] = dghn;
+            }
+            if (t > 0) {
+                base = (long long)ebc * T + (t - 1);
+                n_d = dhseq[base * R + euc]; n_hp = hprev[base * R + euc];
+                n_r = gates[base * 4 * R + euc]; n_z = gates[base * 4 * R + R + euc];
+                n_c = gates[base * 4 * R + 2 * R + euc]; n_g = gates[base * 4 * R + 3 * R + euc];
+            }
+            float a[KSW];
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) a[i] = 0.f;
+            if (cnt > 0) {
+                gu64* first = slab + (long long)(4 * wave + kq) * 16 + j;
+                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)(sidx + 1), a, giveup, lane)) s_fail = 1;
+            }
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wb[i], acc, 0, 0, 0);
+            float(*rd)[4][64] = red[sidx & 1];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) rd[wave][reg][lane] = acc[reg];
+            __syncthreads();
+            if (s_fail) { dead = true; break; }
+            dh = rd[0][wave][lane] + rd[1][wave][lane] + rd[2][wave][lane] + rd[3][wave][lane] + d * z;
+        }
+        if (eok && !dead) dh0[(long long)eb * R + eunit] = dh;
+        __syncthreads();
+    }
+}
+
+int coop_slots(int ntile, int n_st) {
+    int slots = 240 / ntile;           // one workgroup per CU with headroom: every group stays resident
+    if (slots < 1) slots = 1;
+    return slots < n_st ? slots : n_st;
+}
+
 }  // namespace
 
+size_t gru_exchange_bytes(int B, int T, int R) {
+    (void)T;
+    const size_t n_st = (size_t)(B + ROWS - 1) / ROWS;
+    return (size_t)EXCH_HEADER_WORDS * 8 + 2 * n_st * 3 * (size_t)R * ROWS * 8;
+}
+
+static bool coop_ok(int R, const void* exch, size_t exch_bytes, int B, int T) {
+    return exch && R % 4 == 0 && R >= 16 && R <= 256 && (reinterpret_cast<uintptr_t>(exch) & 15) == 0 &&
+           exch_bytes >= gru_exchange_bytes(B, T, R);
+}
+
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-            float* hprev, float* gates, int B, int T, int R) {
+            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes) {
     if (B == 0 || T == 0) return 0;
     if (R % 4 || !aligned16(whh)) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, ntiles = R16 / 16;
+    if (coop_ok(R, exch, exch_bytes, B, T)) {
+        const int n_st = (B + ROWS - 1) / ROWS;
+        const size_t used = (size_t)EXCH_HEADER_WORDS * 8 + 2 * (size_t)n_st * R * ROWS * 8;
+        ProfScope prof(s, KC_GRU_FWD, 2.0 * B * T * 3 * R * R);
+        hipError_t e = hipMemsetAsync(exch, 0, used, s);
+        if (e != hipSuccess) return (int)e;
+        const dim3 grid(ntiles, coop_slots(ntiles, n_st));
+        if ((R >> 2) <= 52)
+            hipLaunchKernelGGL(gru_fwd_coop_kernel<13>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
+                               (unsigned long long*)exch, B, T, R, n_st);
+        else
+            hipLaunchKernelGGL(gru_fwd_coop_kernel<16>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
+                               (unsigned long long*)exch, B, T, R, n_st);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)2 * R16 * ROWS * sizeof(float);
     if (lds > 64 * 1024) return PSVAE_E_SHAPE;
     const int nwaves = ntiles < 16 ? ntiles : 16;
@@ -203,10 +479,25 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
 }
 
 int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
-            float* dgi, float* dgh, float* dh0, int B, int T, int R) {
+            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes) {
     if (B == 0) return 0;
     if (R % 4) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, G16 = (3 * R + 15) & ~15, ntiles = R16 / 16;
+    if (T > 0 && coop_ok(R, exch, exch_bytes, B, T)) {
+        const int n_st = (B + ROWS - 1) / ROWS;
+        ProfScope prof(s, KC_GRU_BWD, 2.0 * B * T * 3 * R * R);
+        hipError_t e = hipMemsetAsync(exch, 0, gru_exchange_bytes(B, T, R), s);
+        if (e != hipSuccess) return (int)e;
+        const dim3 grid(ntiles, coop_slots(ntiles, n_st));
+        if ((3 * R >> 2) <= 152)
+            hipLaunchKernelGGL(gru_bwd_coop_kernel<38>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,
+                               (unsigned long long*)exch, B, T, R, n_st);
+        else
+            hipLaunchKernelGGL(gru_bwd_coop_kernel<48>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,
+                               (unsigned long long*)exch, B, T, R, n_st);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)(ROWS * R16 + ROWS * G16) * sizeof(float);
     if (lds > 64 * 1024) return PSVAE_E_SHAPE;
     const int nwaves = ntiles < 16 ? ntiles : 16;

@@ -134,10 +134,12 @@ int make_gscale(hipStream_t s, const float* g6, const float* w3, float* out4);
 int fill_zero(hipStream_t s, float* p, int64_t count);
 
 // ------------------------------------------------------------ GRU
+// `exch` (gru_exchange_bytes, 16-byte aligned, or NULL) enables the multi-CU recurrence
+size_t gru_exchange_bytes(int B, int T, int R);
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-            float* hprev, float* gates, int B, int T, int R);
+            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes);
 int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
-            float* dgi, float* dgh, float* dh0, int B, int T, int R);
+            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes);
 
 // ------------------------------------------------------------ optimiser
 int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count, float* partials,

@@ -51,6 +51,7 @@ struct WS {
     float *dmulv, *dcond, *dpooled, *GE, *GD, *G0, *DHE, *DHD, *DAE, *DAD, *dX0, *etab_part;
     float *tg_part; size_t tg_part_floats;
     float *scratch, *scratch1, *scratch2; size_t scratch_floats;
+    float* gru_exch; size_t gru_exch_bytes;
     size_t total_floats;
 };
 
@@ -68,6 +69,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
     const size_t chunks = etab_chunks(s.n);
     const int dmax = s.Da > s.Dp ? (s.Da > s.Dq ? s.Da : s.Dq) : (s.Dp > s.Dq ? s.Dp : s.Dq);
     const size_t tg_part = (size_t)(s.NA + s.V2 + s.MP) * 32 * dmax;
+    const size_t gru_exch_bytes = gru_exchange_bytes(s.B, s.T, s.R);
     const Field f[] = {
         {"x0", &WS::X0, n * s.Din},
         {"enc_stack", &WS::XE, n * (s.te + 1) * H}, {"dec_stack", &WS::XD, n * (s.td + 1) * H},
@@ -92,7 +94,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         {"enc_dhid", &WS::DHE, n * s.te * H}, {"dec_dhid", &WS::DHD, n * s.td * H},
         {"enc_dagg", &WS::DAE, n * s.te * H}, {"dec_dagg", &WS::DAD, n * s.td * H},
         {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * tmax * chunks * 4 * H},
-        {"table_grad_part", &WS::tg_part, tg_part},
+        {"table_grad_part", &WS::tg_part, tg_part}, {"gru_exchange", &WS::gru_exch, gru_exch_bytes / 4},
         {"scratch", &WS::scratch, scratch}, {"scratch1", &WS::scratch1, scratch}, {"scratch2", &WS::scratch2, scratch},
     };
     size_t off = 0;
@@ -101,7 +103,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         if (want && want_off && strcmp(want, e.name) == 0) *want_off = (int64_t)off;
         off += (size_t)round_up((int64_t)(e.count ? e.count : 1), 64);
     }
-    if (w) { w->scratch_floats = scratch; w->tg_part_floats = tg_part; w->total_floats = off; }
+    if (w) { w->gru_exch_bytes = gru_exch_bytes; w->scratch_floats = scratch; w->tg_part_floats = tg_part; w->total_floats = off; }
     return off;
 }
 
@@ -326,7 +328,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[1])); PSVAE_TRY(hand_over(st, s2, L->ev[2])); }
     // lane 1: GRU + vocabulary logits + piece loss rows
     PSVAE_TRY(linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, 0, w.scratch1, scf));
-    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R));
+    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes));
     PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
     PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
     // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
@@ -369,7 +371,7 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     // --- lane 1: piece branch (cross-entropy, to_vocab, GRU, latent_to_rnn_hidden)
     PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
-    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R));
+    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes));
     PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
     if (L && hipEventRecord(L->ev[2], s1) != hipSuccess) return (int)hipGetLastError();   // dz_piece, dsemb ready

@@ -117,11 +117,17 @@ def test_segment_pool_forward_backward():
     check_close(xg.grad, xr.grad, 'dx')
 
 
-@pytest.mark.parametrize('B,T,R', [(128, 11, 200), (5, 3, 16), (33, 1, 20), (16, 7, 64)])
-def test_gru_forward_backward(B, T, R):
+@pytest.mark.parametrize('multi_cu', [False, True])
+@pytest.mark.parametrize('B,T,R', [(128, 11, 200), (5, 3, 16), (33, 1, 20), (16, 7, 64), (300, 9, 200), (47, 13, 256),
+                                   (700, 4, 24)])
+def test_gru_forward_backward(B, T, R, multi_cu):
     from ps_vae_amd import _lib
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
+    nx = L.psvae_gru_exchange_bytes(B, T, R) if multi_cu else 0
+    # a dirty exchange buffer: the library must not rely on its previous contents
+    exch = torch.full((max(nx, 16) // 4,), 7, dtype=torch.int32, device=dev())
+    xp = exch.data_ptr() if multi_cu else None
     gi, h0 = _rand(B, T, 3 * R, seed=1), _rand(B, R, seed=2)
     whh, bhh = _rand(3 * R, R, seed=3, scale=R ** -0.5), _rand(3 * R, seed=4, scale=0.1)
     dh = _rand(B, T, R, seed=5)
@@ -141,11 +147,13 @@ def test_gru_forward_backward(B, T, R):
     hseq, hprev = torch.empty(B * T, R, device=d), torch.empty(B * T, R, device=d)
     gates = torch.empty(B * T, 4 * R, device=d)
     _lib.check(L.psvae_gru_forward(g_gi.data_ptr(), g_h0.data_ptr(), g_whh.data_ptr(), g_bhh.data_ptr(), hseq.data_ptr(),
-                                   hprev.data_ptr(), gates.data_ptr(), B, T, R, st))
+                                   hprev.data_ptr(), gates.data_ptr(), B, T, R, xp, nx, st))
     check_close(hseq.view(B, T, R), ref, 'gru output')
     dgi, dgh, dh0 = torch.empty(B * T, 3 * R, device=d), torch.empty(B * T, 3 * R, device=d), torch.empty(B, R, device=d)
     _lib.check(L.psvae_gru_backward(g_dh.data_ptr(), hprev.data_ptr(), gates.data_ptr(), g_whh.data_ptr(), dgi.data_ptr(),
-                                    dgh.data_ptr(), dh0.data_ptr(), B, T, R, st))
+                                    dgh.data_ptr(), dh0.data_ptr(), B, T, R, xp, nx, st))
+    if multi_cu:
+        assert int(exch[0]) == 0, 'a workgroup of the multi-CU recurrence gave up waiting'
     check_close(dgi.view(B, T, 3 * R), gir.grad, 'd gi')
     check_close(dh0, h0r.grad, 'd h0')
     check_close(dgh.view(B * T, 3 * R).t().cpu() @ hprev.cpu(), whr.grad, 'd whh (from dgh, hprev)')

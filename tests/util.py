@@ -62,10 +62,12 @@ def config_from_dims(d, tok):
     }
 
 
-def check_mostly_close(got, want, what, rtol=1e-4, atol=2e-5, max_bad_frac=2e-4):
+def check_mostly_close(got, want, what, rtol=1e-4, atol=2e-5, max_bad_frac=2e-4, max_step=6e-3):
     """For post-optimiser parameters: Adam's first steps move a weight by ~lr * sign(g),
     so an element whose gradient sits at rounding-noise level may differ by up to 2*lr.
-    Everything else must agree; the tolerated fraction of such elements is tiny."""
+    Everything else must agree; the tolerated fraction of such elements is tiny (at least one
+    element, since some tensors are compared on a sample of ~150 values) and none may be further away than
+    `max_step` (3 steps of lr 1e-3, both directions)."""
     got = got.detach().float().cpu().flatten()
     if isinstance(want, dict):
         if 'full' in want:
@@ -75,7 +77,7 @@ def check_mostly_close(got, want, what, rtol=1e-4, atol=2e-5, max_bad_frac=2e-4)
     else:
         ref = want.detach().float().cpu().flatten()
     bad = ~torch.isclose(got, ref, rtol=rtol, atol=atol)
-    frac = float(bad.float().mean()) if bad.numel() else 0.0
-    assert frac <= max_bad_frac, f'{what}: {int(bad.sum())}/{bad.numel()} elements differ (max {float((got - ref).abs().max()):.3e})'
-    if bad.any():
-        assert float((got - ref).abs().max()) <= 2.5e-3, f'{what}: outlier beyond 2*lr'
+    allowed = max(1, int(max_bad_frac * bad.numel()))
+    worst = float((got - ref).abs().max()) if bad.numel() else 0.0
+    assert int(bad.sum()) <= allowed, f'{what}: {int(bad.sum())}/{bad.numel()} elements differ (max {worst:.3e})'
+    assert worst <= max_step, f'{what}: an element moved {worst:.3e} away, more than Adam can move it'
