@@ -145,6 +145,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+    host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -194,7 +195,8 @@ def main():
         'config': {'workload': f'ZINC250K-shape training step, vocab {args.vocab}, hidden 300, batch {args.batch_size} per GPU '
                                f'(fwd + bwd + clip + Adam{" + RCCL grad all-reduce" if world > 1 else ""})',
                    'global_batch': world * args.batch_size, 'parallelism': f'dp{world}', 'params': int(model._n_trained),
-                   'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3},
+                   'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3,
+                   'host_enqueue_ms_per_step': host_enqueue_s / args.steps * 1e3},
         'roofline': roofline,
         'message_passing': {'kernels': mp, 'bound': 'hbm', 'achieved': (mp_bytes / (mp_ms * 1e-3) / 1e9) if mp_ms else None,
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -194,17 +194,15 @@ size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg);
 int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
                                  const int32_t* etype, const float* edge_w, const float* edge_b, float one_plus_eps,
                                  float* out, int ldo, int n, int H, void* stream);
-/* dx[j] = (1+eps) da[j] + sum_{e in rowT j} da[colT[e]] * (x[j] + edge(etypeT[e]) > 0)  (+ pooled-gradient broadcast) */
+/* dx[j] = (1+eps) da[j] + sum_{e in rowT j} da[colT[e]] * (x[j] + edge(etypeT[e]) > 0)  (+ pooled-gradient broadcast).
+ * The same products summed per bond type are the gradient of edge_trans: when d_edge_w [H,4] is given the call
+ * also writes it and d_edge_b [H], using `partial`, scratch of psvae_gine_edge_grad_scratch(n, H) floats. */
+size_t psvae_gine_edge_grad_scratch(int n, int H);
 int psvae_gine_aggregate_backward(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr_t,
                                   const int32_t* col_t, const int32_t* etype_t, const float* edge_w,
                                   const float* edge_b, float one_plus_eps, const float* dpool, int ldp,
-                                  const int32_t* node_graph, float* dx, int lddx, int n, int H, void* stream);
-/* Gradient of edge_trans from one GINE application: d_edge_w[H,4], d_edge_b[H] from da (dL/d aggregated
- * output), the layer input x and the by-target CSR.  `partial` is scratch of psvae_gine_edge_grad_scratch(n, H) floats. */
-size_t psvae_gine_edge_grad_scratch(int n, int H);
-int psvae_gine_edge_grad(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
-                         const int32_t* etype, const float* edge_w, const float* edge_b, float* d_edge_w,
-                         float* d_edge_b, float* partial, int n, int H, void* stream);
+                                  const int32_t* node_graph, float* dx, int lddx, float* d_edge_w, float* d_edge_b,
+                                  float* partial, int n, int H, void* stream);
 /* graph sum-pool: pooled[b] = sum of rows graph_off[b]..graph_off[b+1]. src/modules/encoder.py:64-67 */
 int psvae_segment_pool_forward(const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
                                int B, int width, void* stream);

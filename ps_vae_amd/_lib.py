@@ -113,10 +113,9 @@ def lib():
                                                C.c_int, vp, sz, vp]
     L.psvae_gine_aggregate_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]
     L.psvae_gine_aggregate_backward.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, vp, vp,
-                                                C.c_int, C.c_int, C.c_int, vp]
+                                                C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.psvae_gine_edge_grad_scratch.restype = sz
     L.psvae_gine_edge_grad_scratch.argtypes = [C.c_int, C.c_int]
-    L.psvae_gine_edge_grad.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     L.psvae_segment_pool_forward.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.psvae_gru_exchange_bytes.restype = C.c_size_t
     L.psvae_gru_exchange_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -145,7 +144,7 @@ EXPORTS = (
     'psvae_step_backward', 'psvae_encode', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
-    'psvae_gine_edge_grad', 'psvae_segment_pool_forward',
+    'psvae_segment_pool_forward',
     'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
     'psvae_pack_bound', 'psvae_pack_batch', 'psvae_profile_enable', 'psvae_profile_num_classes',
     'psvae_profile_class_name', 'psvae_profile_collect')

@@ -63,25 +63,26 @@ extern "C" int psvae_gine_aggregate_forward(const float* x, int ldx, const int32
     return gine_agg_fwd((hipStream_t)stream, &g, 1, ldx, ldo, n, H);
 }
 
+extern "C" size_t psvae_gine_edge_grad_scratch(int n, int H) {
+    if (n < 0 || H < 4 || H % 4) return 0;
+    return ((size_t)gine_agg_bwd_blocks(n, H) + ETAB_SEGMENTS) * 4 * H;
+}
+
 extern "C" int psvae_gine_aggregate_backward(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr_t,
                                              const int32_t* col_t, const int32_t* etype_t, const float* edge_w,
                                              const float* edge_b, float one_plus_eps, const float* dpool, int ldp,
-                                             const int32_t* node_graph, float* dx, int lddx, int n, int H, void* stream) {
+                                             const int32_t* node_graph, float* dx, int lddx, float* d_edge_w,
+                                             float* d_edge_b, float* partial, int n, int H, void* stream) {
     if (!dx || (da && (!x || !rowptr_t || !edge_w || !edge_b))) return PSVAE_E_NULL;
+    if (d_edge_w && (!da || !d_edge_b || !partial)) return PSVAE_E_NULL;
     if (n < 0 || H < 4 || lddx < H) return PSVAE_E_SHAPE;
-    AggBwdGroup g{da, x, dx, rowptr_t, col_t, etype_t, edge_w, edge_b, one_plus_eps, dpool, 0};
-    return gine_agg_bwd((hipStream_t)stream, &g, 1, da ? ldda : H, da ? ldx : H, lddx, dpool ? ldp : H, node_graph, n, H);
-}
-
-extern "C" size_t psvae_gine_edge_grad_scratch(int n, int H) { return (size_t)etab_chunks(n) * 4 * H; }
-
-extern "C" int psvae_gine_edge_grad(const float* da, int ldda, const float* x, int ldx, const int32_t* rowptr,
-                                    const int32_t* col, const int32_t* etype, const float* edge_w, const float* edge_b,
-                                    float* d_edge_w, float* d_edge_b, float* partial, int n, int H, void* stream) {
-    if (!da || !x || !rowptr || !edge_w || !edge_b || !d_edge_w || !d_edge_b || !partial) return PSVAE_E_NULL;
-    if (n < 0 || H < 4 || ldda < H || ldx < H) return PSVAE_E_SHAPE;
-    EtabGroup g{da, 0, x, 0, rowptr, col, etype, edge_w, edge_b, d_edge_w, d_edge_b, partial};
-    return gine_etab_grad((hipStream_t)stream, &g, 1, 1, ldda, ldx, n, H, etab_chunks(n));
+    AggBwdGroup g{da, x, dx, rowptr_t, col_t, etype_t, edge_w, edge_b, one_plus_eps, dpool, 0, d_edge_w ? partial : nullptr};
+    PSVAE_TRY(gine_agg_bwd((hipStream_t)stream, &g, 1, da ? ldda : H, da ? ldx : H, lddx, dpool ? ldp : H, node_graph, n, H));
+    if (d_edge_w && n > 0) {
+        EtabFinalGroup e{partial, partial + (size_t)gine_agg_bwd_blocks(n, H) * 4 * H, d_edge_w, d_edge_b};
+        return gine_etab_final((hipStream_t)stream, &e, 1, gine_agg_bwd_blocks(n, H), H);
+    }
+    return 0;
 }
 
 extern "C" int psvae_segment_pool_forward(const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,

@@ -66,124 +66,118 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
         make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
 }
 
-struct AggBwdArgs { AggBwdGroup g[2]; int ldda, ldx, lddx, ldp, n, H4; const int32_t* node_graph; };
+struct AggBwdArgs { AggBwdGroup g[2]; int ldda, ldx, lddx, ldp, n, H4, H4b, nps; const int32_t* node_graph; };
 
+// Backward of the aggregation, by SOURCE node: dx[j] = (1+eps) da[j] + sum over out-edges (j -> i) of
+// da[i] * (x[j] + e(type) > 0)  (+ the pooled-gradient broadcast).  The same products, summed per bond
+// type instead of per node, are the gradient of the edge table, so the kernel accumulates those on the
+// way: a block owns AGG_BWD_PASSES * nps consecutive nodes (nps = 256 / H4b node slots, every thread keeps
+// one channel chunk; rows wider than 256 chunks are split over blockIdx.z in pieces of H4b chunks),
+// combines its slots in order through LDS and writes one [4][H] partial per node block.
 __global__ __launch_bounds__(256) void gine_agg_bwd_kernel(const AggBwdArgs a) {
+    __shared__ float4 part[4][256];
     const AggBwdGroup& g = a.g[blockIdx.y];
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)a.n * a.H4) return;
-    const int j = (int)(t / a.H4), c = (int)(t - (long long)j * a.H4) * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.da) {
-        const EdgeTab et = load_edge_tab(g.edge_w, g.edge_b, c);
-        const float4 xj = ld4(g.x + (long long)j * a.ldx + c);
-        const int e1 = g.rowptr_t[j + 1];
-        for (int e = g.rowptr_t[j]; e < e1; e += 4) {   // groups of 4, as in the forward kernel
-            const int m = e1 - e;
-            const int i0 = g.col_t[e], i1 = m > 1 ? g.col_t[e + 1] : i0, i2 = m > 2 ? g.col_t[e + 2] : i0, i3 = m > 3 ? g.col_t[e + 3] : i0;
-            const int t0 = g.etype_t[e], t1 = m > 1 ? g.etype_t[e + 1] : 0, t2 = m > 2 ? g.etype_t[e + 2] : 0, t3 = m > 3 ? g.etype_t[e + 3] : 0;
-            const float4 d0 = ld4(g.da + (long long)i0 * a.ldda + c), d1 = ld4(g.da + (long long)i1 * a.ldda + c);
-            const float4 d2 = ld4(g.da + (long long)i2 * a.ldda + c), d3 = ld4(g.da + (long long)i3 * a.ldda + c);
-            const float4 e0 = pick(et, t0), ee1 = pick(et, t1), ee2 = pick(et, t2), ee3 = pick(et, t3);
-            acc.x += (xj.x + e0.x > 0.f) ? d0.x : 0.f; acc.y += (xj.y + e0.y > 0.f) ? d0.y : 0.f;
-            acc.z += (xj.z + e0.z > 0.f) ? d0.z : 0.f; acc.w += (xj.w + e0.w > 0.f) ? d0.w : 0.f;
-            if (m > 1) { acc.x += (xj.x + ee1.x > 0.f) ? d1.x : 0.f; acc.y += (xj.y + ee1.y > 0.f) ? d1.y : 0.f;
-                         acc.z += (xj.z + ee1.z > 0.f) ? d1.z : 0.f; acc.w += (xj.w + ee1.w > 0.f) ? d1.w : 0.f; }
-            if (m > 2) { acc.x += (xj.x + ee2.x > 0.f) ? d2.x : 0.f; acc.y += (xj.y + ee2.y > 0.f) ? d2.y : 0.f;
-                         acc.z += (xj.z + ee2.z > 0.f) ? d2.z : 0.f; acc.w += (xj.w + ee2.w > 0.f) ? d2.w : 0.f; }
-            if (m > 3) { acc.x += (xj.x + ee3.x > 0.f) ? d3.x : 0.f; acc.y += (xj.y + ee3.y > 0.f) ? d3.y : 0.f;
-                         acc.z += (xj.z + ee3.z > 0.f) ? d3.z : 0.f; acc.w += (xj.w + ee3.w > 0.f) ? d3.w : 0.f; }
-        }
-        const float4 dj = ld4(g.da + (long long)j * a.ldda + c);
-        acc = make_float4(acc.x + g.ope * dj.x, acc.y + g.ope * dj.y, acc.z + g.ope * dj.z, acc.w + g.ope * dj.w);
-    }
-    if (g.dpool) acc = add4(acc, ld4(g.dpool + (long long)a.node_graph[j] * a.ldp + c));
-    st4(g.dx + (long long)j * a.lddx + c, acc);
-}
-
-// Edge-table gradient, stage 1.  Block (chunk, layer, group) covers a range of target
-// nodes; threadIdx.x = channel-chunk lane, threadIdx.y = quarter of the node range.  Each
-// thread sums da[dst] * (x[src] + e(type) > 0) per bond type over its nodes, the four
-// quarters are combined in order through LDS and written to partial[layer][chunk][4][H].
-struct EtabArgs { EtabGroup g[2]; int t, ldda, ldx, n, H4, chunks; };
-
-__global__ __launch_bounds__(256) void gine_etab_partial_kernel(const EtabArgs a) {
-    __shared__ float4 part[4][4][64];
-    const EtabGroup& g = a.g[blockIdx.z];
-    const int chunk = blockIdx.x, layer = blockIdx.y, tx = threadIdx.x, ty = threadIdx.y;
-    const int per = (a.n + a.chunks - 1) / a.chunks, q = (per + 3) / 4;
-    const int cend = min(a.n, (chunk + 1) * per);
-    const int i0 = min(cend, chunk * per + ty * q), i1 = min(cend, i0 + q);
-    const float* da = g.da + (long long)layer * g.da_layer;
-    const float* x = g.x + (long long)layer * g.x_layer;
-    const int H = a.H4 * 4;
-    float* out = g.partial + ((long long)layer * a.chunks + chunk) * 4 * H;
-    for (int c40 = 0; c40 < a.H4; c40 += 64) {
-        const int c4 = c40 + tx, c = c4 * 4;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-        if (c4 < a.H4) {
-            const EdgeTab et = load_edge_tab(g.edge_w, g.edge_b, c);
-            for (int i = i0; i < i1; ++i) {
-                const int e1 = g.rowptr[i + 1];
-                int e = g.rowptr[i];
-                if (e == e1) continue;
-                const float4 d = ld4(da + (long long)i * a.ldda + c);
-                for (; e < e1; ++e) {
-                    const int tp = g.etype[e];
-                    const float4 xs = ld4(x + (long long)g.col[e] * a.ldx + c);
-                    const float4 ee = pick(et, tp);
-                    const float4 v = make_float4(xs.x + ee.x > 0.f ? d.x : 0.f, xs.y + ee.y > 0.f ? d.y : 0.f,
-                                                 xs.z + ee.z > 0.f ? d.z : 0.f, xs.w + ee.w > 0.f ? d.w : 0.f);
-                    if (tp == 1) s1 = add4(s1, v);
-                    else if (tp == 2) s2 = add4(s2, v);
-                    else if (tp == 3) s3 = add4(s3, v);
-                    else s0 = add4(s0, v);
+    const int tid = threadIdx.x;
+    const int slot = tid / a.H4b, cl = tid - slot * a.H4b, c4 = blockIdx.z * a.H4b + cl, c = c4 * 4;
+    const bool lane_on = slot < a.nps && c4 < a.H4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    EdgeTab et;
+    if (lane_on && g.da) et = load_edge_tab(g.edge_w, g.edge_b, c);
+    const int node0 = blockIdx.x * a.nps * AGG_BWD_PASSES;
+    for (int pass = 0; pass < AGG_BWD_PASSES; ++pass) {
+        const int j = node0 + pass * a.nps + slot;
+        if (!lane_on || j >= a.n) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.da) {
+            const float4 xj = ld4(g.x + (long long)j * a.ldx + c);
+            const int e1 = g.rowptr_t[j + 1];
+            for (int e = g.rowptr_t[j]; e < e1; e += 4) {   // groups of 4, as in the forward kernel
+                const int m = e1 - e;
+                const int i0 = g.col_t[e], i1 = m > 1 ? g.col_t[e + 1] : i0, i2 = m > 2 ? g.col_t[e + 2] : i0, i3 = m > 3 ? g.col_t[e + 3] : i0;
+                const int t0 = g.etype_t[e], t1 = m > 1 ? g.etype_t[e + 1] : 0, t2 = m > 2 ? g.etype_t[e + 2] : 0, t3 = m > 3 ? g.etype_t[e + 3] : 0;
+                const float4 d0 = ld4(g.da + (long long)i0 * a.ldda + c), d1 = ld4(g.da + (long long)i1 * a.ldda + c);
+                const float4 d2 = ld4(g.da + (long long)i2 * a.ldda + c), d3 = ld4(g.da + (long long)i3 * a.ldda + c);
+                const float4 dd[4] = {d0, d1, d2, d3};
+                const int tt[4] = {t0, t1, t2, t3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < m) {
+                        const float4 ee = pick(et, tt[q]);
+                        const float4 v = make_float4(xj.x + ee.x > 0.f ? dd[q].x : 0.f, xj.y + ee.y > 0.f ? dd[q].y : 0.f,
+                                                     xj.z + ee.z > 0.f ? dd[q].z : 0.f, xj.w + ee.w > 0.f ? dd[q].w : 0.f);
+                        acc = add4(acc, v);
+                        if (tt[q] == 1) s1 = add4(s1, v);
+                        else if (tt[q] == 2) s2 = add4(s2, v);
+                        else if (tt[q] == 3) s3 = add4(s3, v);
+                        else s0 = add4(s0, v);
+                    }
                 }
             }
+            const float4 dj = ld4(g.da + (long long)j * a.ldda + c);
+            acc = make_float4(acc.x + g.ope * dj.x, acc.y + g.ope * dj.y, acc.z + g.ope * dj.z, acc.w + g.ope * dj.w);
         }
-        part[ty][0][tx] = s0; part[ty][1][tx] = s1; part[ty][2][tx] = s2; part[ty][3][tx] = s3;
-        __syncthreads();
-        if (c4 < a.H4) {   // thread (tx, ty) finalises bond type ty: quarters added in order
-            const float4 v = add4(add4(add4(part[0][ty][tx], part[1][ty][tx]), part[2][ty][tx]), part[3][ty][tx]);
-            st4(out + ty * H + c, v);
+        if (g.dpool) acc = add4(acc, ld4(g.dpool + (long long)a.node_graph[j] * a.ldp + c));
+        st4(g.dx + (long long)j * a.lddx + c, acc);
+    }
+    if (!g.partial) return;   // uniform over the block
+    part[0][tid] = s0; part[1][tid] = s1; part[2][tid] = s2; part[3][tid] = s3;
+    __syncthreads();
+    if (tid < a.H4b && c4 < a.H4) {
+        float* out = g.partial + (long long)blockIdx.x * 16 * a.H4 + c;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            float4 v = part[tp][tid];
+            for (int sl = 1; sl < a.nps; ++sl) v = add4(v, part[tp][sl * a.H4b + tid]);
+            st4(out + tp * 4 * a.H4, v);
         }
-        __syncthreads();
     }
 }
-// stage 2: d_edge_w[c][type] = sum of the partials in (layer, chunk) order, split into 8 ordered
-// slices per block and combined through LDS; d_edge_b[c] = sum over types.
-__global__ __launch_bounds__(512) void gine_etab_final_kernel(const EtabArgs a) {
-    __shared__ float4 part[8][4][64];
-    const EtabGroup& g = a.g[blockIdx.y];
+
+// Edge-table gradient from the per-block partials, as an ordered two-level sum.  One launch reduces
+// `np` partials [4][H]: blockIdx.z takes a contiguous segment of them, its 16 thread rows take
+// contiguous slices of the segment, rows are combined in order through LDS.  With `final` unset the
+// block writes its [4][H] sum to out_partial[blockIdx.z]; with it set (one segment) it writes
+// d_edge_w[c][type] and d_edge_b[c] = sum over types.
+struct EtabArgs { EtabFinalGroup g[2]; int np, H4, final; };
+
+__global__ __launch_bounds__(256) void gine_etab_reduce_kernel(const EtabArgs a) {
+    __shared__ float4 part[16][4][16];
+    const EtabFinalGroup& g = a.g[blockIdx.y];
     const int H = a.H4 * 4, tx = threadIdx.x, ty = threadIdx.y;
-    const int c4 = blockIdx.x * 64 + tx, c = c4 * 4;
-    const int np = a.t * a.chunks, per = (np + 7) / 8;
-    const int p0 = min(np, ty * per), p1 = min(np, p0 + per);
+    const int c4 = blockIdx.x * 16 + tx, c = c4 * 4;
+    const int seg = (a.np + gridDim.z - 1) / gridDim.z;
+    const int q0 = min(a.np, (int)blockIdx.z * seg), q1 = min(a.np, q0 + seg);
+    const int per = (q1 - q0 + 15) / 16;
+    const int p0 = min(q1, q0 + ty * per), p1 = min(q1, p0 + per);
+    const float* in = a.final ? g.seg_partial : g.partial;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     if (c4 < a.H4) {
+#pragma unroll 4
         for (int p = p0; p < p1; ++p) {
-            const float* src = g.partial + (long long)p * 4 * H + c;
+            const float* src = in + (long long)p * 4 * H + c;
             s0 = add4(s0, ld4(src)); s1 = add4(s1, ld4(src + H)); s2 = add4(s2, ld4(src + 2 * H)); s3 = add4(s3, ld4(src + 3 * H));
         }
     }
     part[ty][0][tx] = s0; part[ty][1][tx] = s1; part[ty][2][tx] = s2; part[ty][3][tx] = s3;
     __syncthreads();
+    if (ty < 4 && c4 < a.H4) {   // thread (tx, ty) adds up bond type ty, slices in order
+        float4 v = part[0][ty][tx];
+#pragma unroll
+        for (int y = 1; y < 16; ++y) v = add4(v, part[y][ty][tx]);
+        if (!a.final) st4(g.seg_partial + ((long long)blockIdx.z * 4 + ty) * H + c, v);
+        part[0][ty][tx] = v;
+    }
+    if (!a.final) return;
+    __syncthreads();
     if (ty == 0 && c4 < a.H4) {
-        float4 w[4];
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
-            float4 v = part[0][tp][tx];
-#pragma unroll
-            for (int y = 1; y < 8; ++y) v = add4(v, part[y][tp][tx]);
-            w[tp] = v;
-        }
+        const float4 w0 = part[0][0][tx], w1 = part[0][1][tx], w2 = part[0][2][tx], w3 = part[0][3][tx];
         // d_edge_w is [H][4]: channel c+k holds (type0..3)
-        st4(g.d_edge_w + (long long)c * 4, make_float4(w[0].x, w[1].x, w[2].x, w[3].x));
-        st4(g.d_edge_w + (long long)(c + 1) * 4, make_float4(w[0].y, w[1].y, w[2].y, w[3].y));
-        st4(g.d_edge_w + (long long)(c + 2) * 4, make_float4(w[0].z, w[1].z, w[2].z, w[3].z));
-        st4(g.d_edge_w + (long long)(c + 3) * 4, make_float4(w[0].w, w[1].w, w[2].w, w[3].w));
-        st4(g.d_edge_b + c, make_float4(((w[0].x + w[1].x) + w[2].x) + w[3].x, ((w[0].y + w[1].y) + w[2].y) + w[3].y,
-                                        ((w[0].z + w[1].z) + w[2].z) + w[3].z, ((w[0].w + w[1].w) + w[2].w) + w[3].w));
+        st4(g.d_edge_w + (long long)c * 4, make_float4(w0.x, w1.x, w2.x, w3.x));
+        st4(g.d_edge_w + (long long)(c + 1) * 4, make_float4(w0.y, w1.y, w2.y, w3.y));
+        st4(g.d_edge_w + (long long)(c + 2) * 4, make_float4(w0.z, w1.z, w2.z, w3.z));
+        st4(g.d_edge_w + (long long)(c + 3) * 4, make_float4(w0.w, w1.w, w2.w, w3.w));
+        st4(g.d_edge_b + c, make_float4(((w0.x + w1.x) + w2.x) + w3.x, ((w0.y + w1.y) + w2.y) + w3.y,
+                                        ((w0.z + w1.z) + w2.z) + w3.z, ((w0.w + w1.w) + w2.w) + w3.w));
     }
 }
 
@@ -378,22 +372,29 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     return 0;
 }
 
+int gine_agg_bwd_blocks(int n, int H) {
+    const int H4 = H / 4, H4b = H4 < 256 ? (H4 < 1 ? 1 : H4) : 256;
+    const int per = (256 / H4b) * AGG_BWD_PASSES;
+    return (n + per - 1) / per;
+}
+
 int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int ldx, int lddx, int ldp,
                  const int32_t* node_graph, int n, int H) {
     if (n == 0) return 0;
     if (H % 4 || ldda % 4 || ldx % 4 || lddx % 4 || ldp % 4) return PSVAE_E_ALIGN;
-    if (ngroups < 1 || ngroups > 2) return PSVAE_E_SHAPE;
+    if (ngroups < 1 || ngroups > 2 || H < 4) return PSVAE_E_SHAPE;
     AggBwdArgs a;
     for (int k = 0; k < ngroups; ++k) {
         a.g[k] = g[k];
         if (!aligned16(g[k].dx) || (g[k].da && (!aligned16(g[k].da) || !aligned16(g[k].x))) ||
-            (g[k].dpool && !aligned16(g[k].dpool))) return PSVAE_E_ALIGN;
+            (g[k].dpool && !aligned16(g[k].dpool)) || (g[k].partial && !aligned16(g[k].partial))) return PSVAE_E_ALIGN;
         if (g[k].dpool && !node_graph) return PSVAE_E_NULL;
+        if (g[k].partial && !g[k].da) return PSVAE_E_NULL;
     }
     if (ngroups == 1) a.g[1] = g[0];
-    a.ldda = ldda; a.ldx = ldx; a.lddx = lddx; a.ldp = ldp; a.n = n; a.H4 = H / 4; a.node_graph = node_graph;
-    const long long items = (long long)n * a.H4;
-    dim3 grid((unsigned)((items + 255) / 256), ngroups);
+    a.ldda = ldda; a.ldx = ldx; a.lddx = lddx; a.ldp = ldp; a.n = n; a.H4 = H / 4; a.H4b = a.H4 < 256 ? a.H4 : 256;
+    a.nps = 256 / a.H4b; a.node_graph = node_graph;
+    dim3 grid((unsigned)gine_agg_bwd_blocks(n, H), ngroups, (a.H4 + a.H4b - 1) / a.H4b);
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += g[k].da ? 3.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1) : 2.0 * n * 4 * H;
     ProfScope prof(s, KC_AGG_BWD, bytes);
@@ -402,17 +403,23 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     return 0;
 }
 
-int gine_etab_grad(hipStream_t s, const EtabGroup* g, int ngroups, int t, int ldda, int ldx, int n, int H, int chunks) {
-    if (H % 4 || ldda % 4 || ldx % 4) return PSVAE_E_ALIGN;
-    if (ngroups < 1 || ngroups > 2 || t < 1 || chunks < 1) return PSVAE_E_SHAPE;
+int gine_etab_final(hipStream_t s, const EtabFinalGroup* g, int ngroups, int np, int H) {
+    if (H % 4) return PSVAE_E_ALIGN;
+    if (ngroups < 1 || ngroups > 2 || np < 1) return PSVAE_E_SHAPE;
     EtabArgs a;
-    for (int k = 0; k < ngroups; ++k) a.g[k] = g[k];
+    for (int k = 0; k < ngroups; ++k) {
+        a.g[k] = g[k];
+        if (!g[k].partial || !g[k].seg_partial || !g[k].d_edge_w || !g[k].d_edge_b) return PSVAE_E_NULL;
+    }
     if (ngroups == 1) a.g[1] = g[0];
-    a.t = t; a.ldda = ldda; a.ldx = ldx; a.n = n; a.H4 = H / 4; a.chunks = chunks;
-    ProfScope prof(s, KC_ETAB, (double)ngroups * t * 2.0 * n * 4 * H);
-    hipLaunchKernelGGL(gine_etab_partial_kernel, dim3(chunks, t, ngroups), dim3(64, 4), 0, s, a);
+    a.H4 = H / 4;
+    const int segs = np < ETAB_SEGMENTS ? np : ETAB_SEGMENTS;
+    ProfScope prof(s, KC_ETAB, (double)ngroups * (np + 2.0 * segs) * 16.0 * H);
+    a.np = np; a.final = 0;
+    hipLaunchKernelGGL(gine_etab_reduce_kernel, dim3((a.H4 + 15) / 16, ngroups, segs), dim3(16, 16), 0, s, a);
     PSVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gine_etab_final_kernel, dim3((H / 4 + 63) / 64, ngroups), dim3(64, 8), 0, s, a);
+    a.np = segs; a.final = 1;
+    hipLaunchKernelGGL(gine_etab_reduce_kernel, dim3((a.H4 + 15) / 16, ngroups, 1), dim3(16, 16), 0, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -81,19 +81,17 @@ struct AggBwdGroup {
     float ope;
     const float* dpool;     // [B, ldp] slice start, or null
     int E;                  // edge count (work accounting only)
+    float* partial;         // null, or [gine_agg_bwd_blocks(n,H)][4][H]: per-block sums for the edge-table gradient
 };
+constexpr int AGG_BWD_PASSES = 2;
+int gine_agg_bwd_blocks(int n, int H);
 int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int ldx, int lddx, int ldp,
                  const int32_t* node_graph, int n, int H);
-struct EtabGroup {
-    const float* da; int64_t da_layer;    // [t][n][H]
-    const float* x; int64_t x_layer;      // layer l input = x + l*x_layer, row stride ldx
-    const int32_t *rowptr, *col, *etype;
-    const float *edge_w, *edge_b;
-    float* d_edge_w; float* d_edge_b;     // outputs [H,4], [H]
-    float* partial;                       // scratch [t*chunks][4][H]
-};
-int gine_etab_grad(hipStream_t s, const EtabGroup* g, int ngroups, int t, int ldda, int ldx, int n, int H, int chunks);
-static inline int etab_chunks(int n) { int c = (n + 31) / 32; return c < 1 ? 1 : (c > 512 ? 512 : c); }
+// d_edge_w [H,4], d_edge_b [H] = ordered sum of np partials [4][H] written by gine_agg_bwd;
+// seg_partial: scratch of ETAB_SEGMENTS * 4 * H floats for the first level of the sum
+constexpr int ETAB_SEGMENTS = 32;
+struct EtabFinalGroup { const float* partial; float* seg_partial; float* d_edge_w; float* d_edge_b; };
+int gine_etab_final(hipStream_t s, const EtabFinalGroup* g, int ngroups, int np, int H);
 
 int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32_t* q, const float* ta,
                   const float* tp, const float* tq, int da, int dp, int dq, float* out, int n);

@@ -66,7 +66,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
     upw(s.H, s.Din); upw(2 * s.H, s.Din); upw(s.G, s.te * s.H); upw(s.V2, s.R); upw(3 * s.R, s.R); upw(3 * s.R, s.Dp);
     upw(s.P2, s.P); upw(s.P, s.P2); upw(s.P2, s.P2); upw(2 * s.Z, s.G); upw(s.Hp, s.Hp); upw(s.Hp, s.Z); upw(s.R, s.Z);
     const size_t scratch = ((size_t)6 << 20) + tmax * maxw;
-    const size_t chunks = etab_chunks(s.n);
+    const size_t chunks = (size_t)gine_agg_bwd_blocks(s.n, s.H);
     const int dmax = s.Da > s.Dp ? (s.Da > s.Dq ? s.Da : s.Dq) : (s.Dp > s.Dq ? s.Dp : s.Dq);
     const size_t tg_part = (size_t)(s.NA + s.V2 + s.MP) * 32 * dmax;
     const size_t gru_exch_bytes = gru_exchange_bytes(s.B, s.T, s.R);
@@ -93,7 +93,7 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         {"enc_g", &WS::GE, n * (s.te + 1) * H}, {"dec_g", &WS::GD, n * (s.td + 1) * H}, {"g0", &WS::G0, n * 2 * H},
         {"enc_dhid", &WS::DHE, n * s.te * H}, {"dec_dhid", &WS::DHD, n * s.td * H},
         {"enc_dagg", &WS::DAE, n * s.te * H}, {"dec_dagg", &WS::DAD, n * s.td * H},
-        {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * tmax * chunks * 4 * H},
+        {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * (tmax * chunks + ETAB_SEGMENTS) * 4 * H},
         {"table_grad_part", &WS::tg_part, tg_part}, {"gru_exchange", &WS::gru_exch, gru_exch_bytes / 4},
         {"scratch", &WS::scratch, scratch}, {"scratch1", &WS::scratch1, scratch}, {"scratch2", &WS::scratch2, scratch},
     };
@@ -173,14 +173,20 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
     return 0;
 }
 
+// per-stack region of the edge-table partials: [t][blocks][4][H]
+static float* etab_region(const Sz& s, const WS& w, int slot) {
+    const size_t tmax = s.te > s.td ? s.te : s.td;
+    return w.etab_part + (size_t)slot * (tmax * gine_agg_bwd_blocks(s.n, s.H) + ETAB_SEGMENTS) * 4 * s.H;
+}
+
 // Backward of 1 or 2 stacks with the same t.  On entry Gr slice t (= [n,H] block t of
 // Gr) holds dL/dx_t.  dpool[q] (or null) is the pooled-output gradient [B, t*H]
 // whose slice l-1 is broadcast into dL/dx_l.  Leaves dL/dx_0 of stack q in
 // w.G0[:, q*H:(q+1)*H] and writes the weight gradients of conv.nn and edge_trans.
 int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch& b, const Stack* k, int ng,
-                    const float* const* dpool, int g0_slot0) {
+                    const float* const* dpool, int g0_slot0, int etab_slot0) {
     const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
-    const size_t nH = (size_t)n * H;
+    const size_t nH = (size_t)n * H, nblk = (size_t)gine_agg_bwd_blocks(n, H);
     const int64_t dG = ng == 2 ? k[1].Gr - k[0].Gr : 0, dDH = ng == 2 ? k[1].DH - k[0].DH : 0;
     const int64_t dDA = ng == 2 ? k[1].DA - k[0].DA : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
     for (int l = t - 1; l >= 0; --l) {
@@ -202,24 +208,23 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
             float* dx = l > 0 ? k[q].Gr + (size_t)l * nH : w.G0 + (size_t)(g0_slot0 + q) * H;
             const float* dp = (l > 0 && dpool && dpool[q]) ? dpool[q] + (size_t)(l - 1) * H : nullptr;
             ag[q] = AggBwdGroup{k[q].DA + (size_t)l * nH, k[q].X + (size_t)l * H, dx, k[q].rowptr_t, k[q].col_t,
-                                k[q].etype_t, k[q].edge_w, k[q].edge_b, k[q].ope, dp, k[q].E};
+                                k[q].etype_t, k[q].edge_w, k[q].edge_b, k[q].ope, dp, k[q].E,
+                                etab_region(s, w, etab_slot0 + q) + (size_t)l * nblk * 4 * H};
         }
         PSVAE_TRY(gine_agg_bwd(st, ag, ng, H, ldx, l > 0 ? H : 2 * H, t * H, b.node_graph, n, H));
     }
     return 0;
 }
 
-// edge_trans gradients of 1 or 2 stacks with the same t (after stacks_backward)
+// edge_trans gradients of 1 or 2 stacks with the same t, from the partials stacks_backward left behind
 int stacks_edge_grads(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng, int slot0) {
-    const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
-    const size_t nH = (size_t)n * H;
-    EtabGroup eg[2];
-    const int chunks = etab_chunks(n);
-    const int tmax = s.te > s.td ? s.te : s.td;
-    for (int q = 0; q < ng; ++q)
-        eg[q] = EtabGroup{k[q].DA, (int64_t)nH, k[q].X, (int64_t)H, k[q].rowptr, k[q].col, k[q].etype, k[q].edge_w, k[q].edge_b,
-                          k[q].g_edge_w, k[q].g_edge_b, w.etab_part + (size_t)(slot0 + q) * tmax * chunks * 4 * H};
-    return gine_etab_grad(st, eg, ng, t, H, ldx, n, H, chunks);
+    EtabFinalGroup eg[2];
+    const size_t np = (size_t)k[0].t * gine_agg_bwd_blocks(s.n, s.H);
+    for (int q = 0; q < ng; ++q) {
+        float* region = etab_region(s, w, slot0 + q);
+        eg[q] = EtabFinalGroup{region, region + np * 4 * s.H, k[q].g_edge_w, k[q].g_edge_b};
+    }
+    return gine_etab_final(st, eg, ng, (int)np, s.H);
 }
 
 // Side streams ("lanes") for the branches of the step that do not depend on each other: the
@@ -239,8 +244,13 @@ Lanes* get_lanes() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!per_device[dev]) {
         Lanes* l = new Lanes();
-        bool ok = hipStreamCreateWithFlags(&l->s1, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&l->s2, hipStreamNonBlocking) == hipSuccess;
+        // lane 1 carries the GRU (on the critical path): highest priority; lane 2 carries weight-gradient
+        // products nobody waits for until the end of the step: lowest, so they fill CUs the chain leaves idle
+        int least = 0, greatest = 0;
+        const char* pe = getenv("PSVAE_LANE_PRIORITY");
+        if (!(pe && pe[0] == '0')) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        bool ok = hipStreamCreateWithPriority(&l->s1, hipStreamNonBlocking, greatest) == hipSuccess &&
+                  hipStreamCreateWithPriority(&l->s2, hipStreamNonBlocking, least) == hipSuccess;
         for (int i = 0; ok && i < 12; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { delete l; disabled = 1; return nullptr; }
         per_device[dev] = l;
@@ -426,15 +436,15 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
     {
         AggBwdGroup top{nullptr, nullptr, w.GE + (size_t)s.te * nH, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f,
-                        w.dpooled + (size_t)(s.te - 1) * s.H, 0};
+                        w.dpooled + (size_t)(s.te - 1) * s.H, 0, nullptr};
         PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
     }
     const float* dpool[2] = {w.dpooled, nullptr};
     if (s.te == s.td) {
-        PSVAE_TRY(stacks_backward(st, s, w, b, k, 2, dpool, 0));
+        PSVAE_TRY(stacks_backward(st, s, w, b, k, 2, dpool, 0, 0));
     } else {
-        PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0));
-        PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1));
+        PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0, 0));
+        PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1, 1));
     }
     // weight gradients of the shared GINE MLPs (sum over the t applications): encoder on lane 1,
     // decoder-side encoder on lane 2, beside node_trans / edge_trans / embedding tables on main

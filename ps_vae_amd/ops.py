@@ -110,15 +110,13 @@ class GineAggregateFn(torch.autograd.Function):
         csr, n, H = ctx.csr, x.shape[0], x.shape[1]
         da = _f32c(da)
         dx = torch.empty_like(x)
+        dw, db = torch.zeros_like(edge_w), torch.zeros_like(edge_b)
+        part = torch.empty(max(1, L.psvae_gine_edge_grad_scratch(n, H)), dtype=torch.float32, device=x.device)
         _lib.check(L.psvae_gine_aggregate_backward(da.data_ptr(), H, x.data_ptr(), H, csr.rowptr_t.data_ptr(),
                                                    csr.col_t.data_ptr(), csr.etype_t.data_ptr(), edge_w.data_ptr(),
-                                                   edge_b.data_ptr(), ctx.ope, None, 0, None, dx.data_ptr(), H, n, H,
-                                                   _stream()), 'psvae_gine_aggregate_backward')
-        dw, db = torch.empty_like(edge_w), torch.empty_like(edge_b)
-        part = torch.empty(L.psvae_gine_edge_grad_scratch(n, H), dtype=torch.float32, device=x.device)
-        _lib.check(L.psvae_gine_edge_grad(da.data_ptr(), H, x.data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                          csr.etype.data_ptr(), edge_w.data_ptr(), edge_b.data_ptr(), dw.data_ptr(),
-                                          db.data_ptr(), part.data_ptr(), n, H, _stream()), 'psvae_gine_edge_grad')
+                                                   edge_b.data_ptr(), ctx.ope, None, 0, None, dx.data_ptr(), H,
+                                                   dw.data_ptr(), db.data_ptr(), part.data_ptr(), n, H, _stream()),
+                   'psvae_gine_aggregate_backward')
         return dx, dw, db, None, None
 
 
@@ -147,6 +145,7 @@ class SegmentPoolFn(torch.autograd.Function):
         W = dp.shape[1]
         dx = torch.empty(ctx.n, W, dtype=torch.float32, device=dp.device)
         _lib.check(L.psvae_gine_aggregate_backward(None, 0, None, 0, None, None, None, None, None, 1.0, dp.data_ptr(), W,
-                                                   node_graph.data_ptr(), dx.data_ptr(), W, ctx.n, W, _stream()),
+                                                   node_graph.data_ptr(), dx.data_ptr(), W, None, None, None, ctx.n, W,
+                                                   _stream()),
                    'psvae_gine_aggregate_backward(pool broadcast)')
         return dx, None, None
