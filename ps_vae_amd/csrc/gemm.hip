@@ -17,7 +17,12 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 64 + 4;
+constexpr int BM = 64, BN = 64, BK = 32;
+// LDS row pitch of a [k][row] operand image.  A tile that arrives with the reduction index contiguous is
+// written element by element (lane -> k = 4*(q&7).., row = q>>3): pitch 65 spreads those writes over all
+// 32 banks.  A tile that arrives with the output index contiguous is written as float4 rows: pitch 68 keeps
+// them 16-byte aligned.  MFMA operand reads (32 consecutive rows of one k) are conflict-free for any pitch.
+template <bool T> struct Pitch { static constexpr int value = T ? 68 : 65; };
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct GemmP {
@@ -33,66 +38,74 @@ struct GemmP {
     long long slab_stride;
 };
 
-// This thread's 8 elements of one 64 x 32 operand tile, as loaded, plus per-element flags.
-// The flags are applied only when the stage is written to LDS: touching a loaded value
-// earlier would make the compiler wait for the load right after issuing it.
-struct Stage { float4 v0, v1; unsigned flags; };   // bits 0-3 / 4-7: element valid; bits 8-11 / 12-15: element is the ones column
+// One operand of the product as this workgroup sees it: X[o][r] (T = false, reduction index contiguous) or
+// X[r][o] (T = true, output index contiguous); the tile covers outputs o0 .. o0+63.
+struct TileGeo { const float* X; int ld, o0, o_lim, r_lim, ones_col; };
 
-// One float4 of an operand tile, without branches (a branch around a load makes the
-// compiler drain the whole load queue at the join, which would serialise the prefetch):
-// the address is clamped into the matrix, the load is unconditional, and elements that
-// lie outside the tile's valid range are flagged to be zeroed later.
-//  !T: X[o*ld + r]: slot q -> row o = o0 + q/8, r = r0 + 4*(q%8) .. +3   (vector along r)
-//   T: X[r*ld + o]: slot q -> r = r0 + q/16,   o = o0 + 4*(q%16) .. +3   (vector along o)
-// VEC: base 16-byte aligned and ld % 4 == 0, so a float4 that starts inside a row stays
-// inside that row's ld floats even when it overhangs the valid width.
-template <bool T, bool VEC>
-__device__ __forceinline__ float4 load_quad(const float* __restrict__ X, int ld, int o0, int o_lim, int r0, int r_lim,
-                                            int q, int ones_col, unsigned& flags) {
-    const int o = T ? o0 + ((q & 15) << 2) : o0 + (q >> 3);
+// This thread's 8 elements (two float4 "quads") of one 64 x 32 operand tile, as loaded.
+struct Stage { float4 v0, v1; };
+
+//  !T: slot q -> row o = o0 + q/8, r = r0 + 4*(q%8) .. +3    (vector along r)
+//   T: slot q -> r = r0 + q/16,    o = o0 + 4*(q%16) .. +3   (vector along o)
+// Validity (bits 0-3) and "is the ones column" (bits 8-11) of the 4 elements of quad q.
+template <bool T>
+__device__ __forceinline__ unsigned quad_flags(const TileGeo& g, int r0, int q) {
+    const int o = T ? g.o0 + ((q & 15) << 2) : g.o0 + (q >> 3);
     const int r = T ? r0 + (q >> 4) : r0 + ((q & 7) << 2);
     const int first = T ? o : r;                                              // index along the vector
-    const int lim = T ? (ones_col >= 0 ? ones_col : o_lim) : r_lim;           // valid extent along the vector
-    const bool line_ok = T ? (r < r_lim) : (o < o_lim);
-    const bool any = line_ok && first < lim;
-    const float* p = X + (any ? (long long)(T ? r : o) * ld + first : 0);
-    const bool ok1 = any && first + 1 < lim, ok2 = any && first + 2 < lim, ok3 = any && first + 3 < lim;
-    flags = (any ? 1u : 0u) | (ok1 ? 2u : 0u) | (ok2 ? 4u : 0u) | (ok3 ? 8u : 0u);
-    if (T && ones_col >= 0 && line_ok) {
-        const int d = ones_col - o;
+    const int lim = T ? (g.ones_col >= 0 ? g.ones_col : g.o_lim) : g.r_lim;   // valid extent along the vector
+    const bool line_ok = T ? (r < g.r_lim) : (o < g.o_lim);
+    const int left = line_ok ? lim - first : 0;                               // valid elements from `first` on
+    unsigned flags = left >= 4 ? 0xFu : (left <= 0 ? 0u : (1u << left) - 1u);
+    if (T && g.ones_col >= 0 && line_ok) {
+        const int d = g.ones_col - o;
         if (d >= 0 && d < 4) flags |= 0x100u << d;
     }
+    return flags;
+}
+
+// One float4 of an operand tile, without branches (a branch around a load makes the compiler wait at the
+// join for loads it has just issued, which would serialise the prefetch): the address is clamped into the
+// matrix and the load is unconditional; what lies outside the valid range is zeroed when the stage is
+// written to LDS.  VEC: base 16-byte aligned and ld % 4 == 0, so a float4 that starts inside a row stays
+// inside that row's ld floats even when it overhangs the valid width.
+template <bool T, bool VEC>
+__device__ __forceinline__ float4 load_quad(const TileGeo& g, int r0, int q) {
+    const int o = T ? g.o0 + ((q & 15) << 2) : g.o0 + (q >> 3);
+    const int r = T ? r0 + (q >> 4) : r0 + ((q & 7) << 2);
+    const int first = T ? o : r;
+    const int lim = T ? (g.ones_col >= 0 ? g.ones_col : g.o_lim) : g.r_lim;
+    const bool any = (T ? (r < g.r_lim) : (o < g.o_lim)) && first < lim;
+    const float* p = g.X + (any ? (long long)(T ? r : o) * g.ld + first : 0);
     float4 v;
     if (VEC) {
         v = *reinterpret_cast<const float4*>(p);
     } else {
         // unaligned operand: four scalar loads, each clamped to the first element when out of range
+        const bool ok1 = any && first + 1 < lim, ok2 = any && first + 2 < lim, ok3 = any && first + 3 < lim;
         v.x = p[0]; v.y = p[ok1 ? 1 : 0]; v.z = p[ok2 ? 2 : 0]; v.w = p[ok3 ? 3 : 0];
     }
     return v;
 }
 
 template <bool T, bool VEC>
-__device__ __forceinline__ Stage load_stage(const float* __restrict__ X, int ld, int o0, int o_lim, int r0, int r_lim,
-                                            int tid, int ones_col) {
+__device__ __forceinline__ Stage load_stage(const TileGeo& g, int r0, int tid) {
     Stage s;
-    unsigned f0, f1;
-    s.v0 = load_quad<T, VEC>(X, ld, o0, o_lim, r0, r_lim, tid, ones_col, f0);
-    s.v1 = load_quad<T, VEC>(X, ld, o0, o_lim, r0, r_lim, tid + 256, ones_col, f1);
-    s.flags = (f0 & 0xFu) | ((f1 & 0xFu) << 4) | (f0 & 0xF00u) | ((f1 & 0xF00u) << 4);
+    s.v0 = load_quad<T, VEC>(g, r0, tid);
+    s.v1 = load_quad<T, VEC>(g, r0, tid + 256);
     return s;
 }
 
-__device__ __forceinline__ float4 apply_flags(float4 v, unsigned valid, unsigned ones) {
-    v.x = (valid & 1u) ? v.x : 0.f; v.y = (valid & 2u) ? v.y : 0.f;
-    v.z = (valid & 4u) ? v.z : 0.f; v.w = (valid & 8u) ? v.w : 0.f;
-    v.x = (ones & 1u) ? 1.f : v.x; v.y = (ones & 2u) ? 1.f : v.y;
-    v.z = (ones & 4u) ? 1.f : v.z; v.w = (ones & 8u) ? 1.f : v.w;
+__device__ __forceinline__ float4 apply_flags(float4 v, unsigned flags) {
+    v.x = (flags & 1u) ? v.x : 0.f; v.y = (flags & 2u) ? v.y : 0.f;
+    v.z = (flags & 4u) ? v.z : 0.f; v.w = (flags & 8u) ? v.w : 0.f;
+    v.x = (flags & 0x100u) ? 1.f : v.x; v.y = (flags & 0x200u) ? 1.f : v.y;
+    v.z = (flags & 0x400u) ? 1.f : v.z; v.w = (flags & 0x800u) ? 1.f : v.w;
     return v;
 }
 
 template <bool T>
-__device__ __forceinline__ void store_quad(float (*s)[LDS_LD], float4 v, int q) {
+__device__ __forceinline__ void store_quad(float (*s)[Pitch<T>::value], float4 v, int q) {
     if (!T) {
         const int row = q >> 3, k = (q & 7) << 2;
         s[k][row] = v.x; s[k + 1][row] = v.y; s[k + 2][row] = v.z; s[k + 3][row] = v.w;
@@ -100,13 +113,23 @@ __device__ __forceinline__ void store_quad(float (*s)[LDS_LD], float4 v, int q) 
         *reinterpret_cast<float4*>(&s[q >> 4][(q & 15) << 2]) = v;
     }
 }
+// Write a loaded stage into its LDS image.  A tile that lies wholly inside the matrix (the common case,
+// decided per workgroup and K-step, so the branch is uniform) is written as loaded; any other tile has
+// its out-of-range elements zeroed and the ones column filled in.
 template <bool T>
-__device__ __forceinline__ void store_stage(float (*s)[LDS_LD], const Stage& st, int tid) {
-    store_quad<T>(s, apply_flags(st.v0, st.flags & 0xFu, (st.flags >> 8) & 0xFu), tid);
-    store_quad<T>(s, apply_flags(st.v1, (st.flags >> 4) & 0xFu, (st.flags >> 12) & 0xFu), tid + 256);
+__device__ __forceinline__ void store_stage(float (*s)[Pitch<T>::value], const Stage& st, const TileGeo& g, int r0, int tid) {
+    const int olim = T ? (g.ones_col >= 0 ? g.ones_col : g.o_lim) : g.o_lim;
+    if (g.o0 + BM <= olim && r0 + BK <= g.r_lim) {
+        store_quad<T>(s, st.v0, tid);
+        store_quad<T>(s, st.v1, tid + 256);
+    } else {
+        store_quad<T>(s, apply_flags(st.v0, quad_flags<T>(g, r0, tid)), tid);
+        store_quad<T>(s, apply_flags(st.v1, quad_flags<T>(g, r0, tid + 256)), tid + 256);
+    }
 }
 
-__device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LDS_LD], const float (*sb)[LDS_LD], int arow, int brow,
+template <int LA, int LB>
+__device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LA], const float (*sb)[LB], int arow, int brow,
                                               int kh, floatx16 acc) {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -119,8 +142,8 @@ __device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LDS_LD], const f
 
 template <bool AT, bool BT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
-    __shared__ __attribute__((aligned(16))) float sA[2][BK][LDS_LD];
-    __shared__ __attribute__((aligned(16))) float sB[2][BK][LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sA[2][BK][Pitch<AT>::value];
+    __shared__ __attribute__((aligned(16))) float sB[2][BK][Pitch<BT>::value];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int z = blockIdx.z, seg = z / p.splits, sp = z - seg * p.splits;
@@ -137,40 +160,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
 
     if (nk > 0) {
         const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = lane >> 5;
-        // register stages: E holds the next odd tile, O... named so that every access is static
-        Stage a0 = load_stage<AT, VEC>(A, p.lda, m0, p.M, rbeg, rend, tid, -1);
-        Stage b0 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, rbeg, rend, tid, p.ones_col);
-        Stage a1 = load_stage<AT, VEC>(A, p.lda, m0, p.M, rbeg + BK, rend, tid, -1);   // empty (zeros) when nk == 1
-        Stage b1 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, rbeg + BK, rend, tid, p.ones_col);
-        store_stage<AT>(sA[0], a0, tid);
-        store_stage<BT>(sB[0], b0, tid);
+        const TileGeo ga{A, p.lda, m0, p.M, rend, -1}, gb{B, p.ldb, n0, p.N, rend, p.ones_col};
+        // two register stages, named so that every access is static: stage (kt & 1) carries tile kt
+        Stage a0 = load_stage<AT, VEC>(ga, rbeg, tid);
+        Stage b0 = load_stage<BT, VEC>(gb, rbeg, tid);
+        Stage a1 = load_stage<AT, VEC>(ga, rbeg + BK, tid);   // all zeros once stored when nk == 1
+        Stage b1 = load_stage<BT, VEC>(gb, rbeg + BK, tid);
+        store_stage<AT>(sA[0], a0, ga, rbeg, tid);
+        store_stage<BT>(sB[0], b0, gb, rbeg, tid);
         __syncthreads();
-        // invariant at the top of iteration kt: LDS buffer kt&1 holds tile kt, stage (kt+1)&1 holds tile kt+1
+        // Invariant at the top of an iteration: LDS buffer 0 holds tile kt, stage 1 holds tile kt+1 (in flight).
+        // Loads and LDS stores are unconditional: tiles past the end of the reduction range are fetched from a
+        // clamped address and stored as zeros (a branch around a load makes the compiler wait at the join for
+        // the loads it has just issued).  The loop always runs whole pairs of K-steps; a pair's second tile may
+        // be such an all-zero tile.
         for (int kt = 0; kt < nk; kt += 2) {
-            // ---- even half: compute tile kt from buffer 0; stage 0 is free -> fetch tile kt+2 into it
-            if (kt + 2 < nk) {
-                const int r0 = rbeg + (kt + 2) * BK;
-                a0 = load_stage<AT, VEC>(A, p.lda, m0, p.M, r0, rend, tid, -1);
-                b0 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, r0, rend, tid, p.ones_col);
-            }
+            const int r1 = rbeg + (kt + 1) * BK, r2 = r1 + BK, r3 = r2 + BK;
+            // even half: compute tile kt from buffer 0; stage 0 is free -> fetch tile kt+2 into it
+            a0 = load_stage<AT, VEC>(ga, r2, tid);
+            b0 = load_stage<BT, VEC>(gb, r2, tid);
             acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
-            if (kt + 1 < nk) {
-                store_stage<AT>(sA[1], a1, tid);
-                store_stage<BT>(sB[1], b1, tid);
-            }
+            store_stage<AT>(sA[1], a1, ga, r1, tid);
+            store_stage<BT>(sB[1], b1, gb, r1, tid);
             __syncthreads();
-            if (kt + 1 >= nk) break;
-            // ---- odd half: compute tile kt+1 from buffer 1; stage 1 is free -> fetch tile kt+3
-            if (kt + 3 < nk) {
-                const int r0 = rbeg + (kt + 3) * BK;
-                a1 = load_stage<AT, VEC>(A, p.lda, m0, p.M, r0, rend, tid, -1);
-                b1 = load_stage<BT, VEC>(B, p.ldb, n0, p.N, r0, rend, tid, p.ones_col);
-            }
+            // odd half: compute tile kt+1 from buffer 1; stage 1 is free -> fetch tile kt+3
+            a1 = load_stage<AT, VEC>(ga, r3, tid);
+            b1 = load_stage<BT, VEC>(gb, r3, tid);
             acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
-            if (kt + 2 < nk) {
-                store_stage<AT>(sA[0], a0, tid);
-                store_stage<BT>(sB[0], b0, tid);
-            }
+            store_stage<AT>(sA[0], a0, ga, r2, tid);
+            store_stage<BT>(sB[0], b0, gb, r2, tid);
             __syncthreads();
         }
     }
