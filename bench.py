@@ -94,18 +94,31 @@ def main():
     ap.add_argument('--shape', default='zinc')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=10)
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' rehearses the multi-rank "
+                    "path on a box with fewer GPUs than ranks (ranks then share devices)")
     args = ap.parse_args()
+    if os.environ.get('PSVAE_BENCH_WATCHDOG'):     # seconds; on expiry every thread's stack goes to stderr and the run ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['PSVAE_BENCH_WATCHDOG']), exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    n_dev = torch.cuda.device_count()
+    if world > 1 and args.backend == 'nccl' and n_dev < world:
+        raise SystemExit(f'{world} ranks over RCCL need {world} GPUs, this node shows {n_dev}')
+    dev = torch.device('cuda', local_rank % max(n_dev, 1))
+    torch.cuda.set_device(dev)
+    # Rehearsal only (gloo, fewer GPUs than ranks): processes that share a GPU must not block on a collective
+    # while their own queue still holds work that waits for it, or the other process may never get the GPU.
+    shared_gpu = world > max(n_dev, 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+        if args.backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     tok = Tokenizer.synthetic(args.vocab)
     torch.manual_seed(2021)
@@ -123,13 +136,19 @@ def main():
         batch = batches[i % n_distinct]
         nb = batch['_native']
         if world > 1:
+            if shared_gpu:
+                torch.cuda.synchronize()
             reducer.reduce_denoms(local_denoms[i % n_distinct], out=nb.denoms)
         eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
         opt.zero_grad()
         loss = model.training_step(batch, eps=eps)
         loss.backward()
         if world > 1:
+            if shared_gpu:
+                torch.cuda.synchronize()
             reducer.reduce_grads(model.flat_buffers()[1])
+            if shared_gpu:
+                torch.cuda.synchronize()
         opt.step()
         model.global_step += 1
         return loss
@@ -163,9 +182,13 @@ def main():
     classes = _lib.profile_collect()
     L.psvae_profile_enable(0)
 
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
+    comm = 'RCCL' if args.backend == 'nccl' else args.backend
     value = world * args.batch_size * args.steps / elapsed
     table = {}
     for name, (ms, work, cnt) in classes.items():
@@ -193,7 +216,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'ZINC250K-shape training step, vocab {args.vocab}, hidden 300, batch {args.batch_size} per GPU '
-                               f'(fwd + bwd + clip + Adam{" + RCCL grad all-reduce" if world > 1 else ""})',
+                               f'(fwd + bwd + clip + Adam{f" + grad all-reduce over {comm}" if world > 1 else ""})',
                    'global_batch': world * args.batch_size, 'parallelism': f'dp{world}', 'params': int(model._n_trained),
                    'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3,
                    'host_enqueue_ms_per_step': host_enqueue_s / args.steps * 1e3},

@@ -443,7 +443,10 @@ size_t gru_exchange_bytes(int B, int T, int R) {
 }
 
 static bool coop_ok(int R, const void* exch, size_t exch_bytes, int B, int T) {
-    return exch && R % 4 == 0 && R >= 16 && R <= 256 && (reinterpret_cast<uintptr_t>(exch) & 15) == 0 &&
+    // PSVAE_GRU_MULTI_CU=0 forces the single-CU kernels (e.g. on a GPU that other processes keep busy:
+    // the multi-CU kernels need all workgroups of a sequence tile resident at the same time)
+    static const bool enabled = [] { const char* e = getenv("PSVAE_GRU_MULTI_CU"); return !(e && e[0] == '0'); }();
+    return enabled && exch && R % 4 == 0 && R >= 16 && R <= 256 && (reinterpret_cast<uintptr_t>(exch) & 15) == 0 &&
            exch_bytes >= gru_exchange_bytes(B, T, R);
 }
 

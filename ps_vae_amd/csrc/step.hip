@@ -244,11 +244,13 @@ Lanes* get_lanes() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!per_device[dev]) {
         Lanes* l = new Lanes();
-        // lane 1 carries the GRU (on the critical path): highest priority; lane 2 carries weight-gradient
-        // products nobody waits for until the end of the step: lowest, so they fill CUs the chain leaves idle
+        // PSVAE_LANE_PRIORITY=1: lane 1 (GRU, on the critical path) gets the highest stream priority and lane 2
+        // (weight-gradient products nobody waits for until the end of the step) the lowest.  Worth ~2 % on a
+        // GPU this process owns; off by default because with a second process on the same GPU the
+        // low-priority lane was observed never to finish.
         int least = 0, greatest = 0;
         const char* pe = getenv("PSVAE_LANE_PRIORITY");
-        if (!(pe && pe[0] == '0')) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (pe && pe[0] == '1') (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         bool ok = hipStreamCreateWithPriority(&l->s1, hipStreamNonBlocking, greatest) == hipSuccess &&
                   hipStreamCreateWithPriority(&l->s2, hipStreamNonBlocking, least) == hipSuccess;
         for (int i = 0; ok && i < 12; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;

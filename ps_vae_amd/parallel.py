@@ -36,12 +36,22 @@ class GradReducer:
         self.bounds = list(bounds)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # gloo moves GPU tensors through host memory anyway; doing that copy here keeps gloo on its CPU path
+        self.stage_on_host = dist.is_initialized() and dist.get_backend(group) == 'gloo'
+
+    def _all_reduce(self, t, async_op=False):
+        if self.stage_on_host and t.is_cuda:
+            host = t.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def reduce_denoms(self, local_denoms, out=None):
         """Global loss denominators: sum of the per-rank counts."""
         out = local_denoms.clone() if out is None else out.copy_(local_denoms)
         if self.world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(out)
         return out
 
     def reduce_grads(self, flat_grads, async_op=False):
@@ -50,7 +60,9 @@ class GradReducer:
         works = []
         for lo, hi in zip(self.bounds[:-1], self.bounds[1:]):
             if hi > lo:
-                works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+                work = self._all_reduce(flat_grads[lo:hi], async_op=async_op)
+                if work is not None:
+                    works.append(work)
         return works if async_op else []
 
 

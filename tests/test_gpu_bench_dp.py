@@ -1,0 +1,28 @@
+"""The benchmark's multi-rank path on the one GPU of the test box: two ranks share the device and
+exchange through gloo (RCCL needs one GPU per rank).  Checks that denominators and gradients are
+reduced every step and that rank 0 prints the result line for the whole job."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_over_gloo():
+    env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+           '--backend', 'gloo', '--no-cpu-baseline', '--profile-steps', '1']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['global_batch'] == 256
+    assert res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']   # finite, not NaN
+    assert res['roofline']['frac'] > 0
