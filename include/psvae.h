@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 1
+#define PSVAE_ABI_VERSION 2
 
 enum {
     PSVAE_OK = 0,
@@ -120,6 +120,14 @@ typedef struct psvae_batch {
     const float *denoms;         /* [4] loss denominators: non-pad target tokens, S, B, B*n_props.
                                     Data-parallel callers all-reduce these so every rank
                                     divides by the global-batch counts. */
+    /* Decoder-only mode = VAEPieceDecoder.forward called on its own (src/modules/vae_piece_decoder.py:71-126):
+     * when `conds` is set the step takes the graph conditions [B, G] from it instead of running the encoder
+     * (the in_* arrays then describe the edges the caller passed), skips the property head (loss 0) and
+     * needs none of the encoder / predictor fields of psvae_params; backward writes dL/dconds into d_conds
+     * and adds d_z (dL/dz from the caller's use of the returned z, may be NULL) to the latent gradient. */
+    const float *conds;          /* [B, G] or NULL */
+    float *d_conds;              /* [B, G], backward output in decoder-only mode */
+    const float *d_z;            /* [B, Z] or NULL */
 } psvae_batch;
 
 /* ---- whole training step ---------------------------------------------------

@@ -163,11 +163,13 @@ def gru_sequence(x_seq, h0, p):
     return torch.stack(outs, dim=1)
 
 
-def forward(p, d, batch, eps, keep=None):
+def forward(p, d, batch, eps, keep=None, conds=None):
     """`PSVAEModel.forward` (`src/pl_models/ps_vae_model.py:33-58`) with the
     decoder's `forward` (`src/modules/vae_piece_decoder.py:71-117`) inlined.
     `eps` replaces the `randn_like` draw of `rsample` (:61).  Returns a dict of
-    the five losses; intermediate tensors are added to `keep` when given."""
+    the five losses; intermediate tensors are added to `keep` when given.
+    With `conds` the encoder is skipped and the decoder runs on the given graph
+    conditions, as when `VAEPieceDecoder.forward` is called on its own (:71)."""
     A = keep if keep is not None else {}
     x_ids, xp, xq = batch['x'], batch['x_pieces'], batch['x_pos']
     B, N = x_ids.shape
@@ -179,11 +181,15 @@ def forward(p, d, batch, eps, keep=None):
     node_dim = x0.shape[-1]
     graph_ids = torch.repeat_interleave(torch.arange(B), N)
     ei, ea = batch['edge_index'], batch['edge_attr']
-    enc_layers = embed_node(x0.view(-1, node_dim), ei, ea, p, 'encoder.', d['t_enc'])
-    A['enc_layers'] = enc_layers
-    all_x = torch.cat(enc_layers[1:], dim=-1)
-    pooled, cond = embed_graph(all_x, graph_ids, batch['atom_mask'].flatten(), p, 'encoder.')
-    A['pooled'], A['cond'] = pooled, cond
+    if conds is None:
+        enc_layers = embed_node(x0.view(-1, node_dim), ei, ea, p, 'encoder.', d['t_enc'])
+        A['enc_layers'] = enc_layers
+        all_x = torch.cat(enc_layers[1:], dim=-1)
+        pooled, cond = embed_graph(all_x, graph_ids, batch['atom_mask'].flatten(), p, 'encoder.')
+        A['pooled'] = pooled
+    else:
+        cond = conds
+    A['cond'] = cond
     # rsample (vae_piece_decoder.py:56-63)
     z_mean = F.linear(cond, p['decoder.W_mean.weight'], p['decoder.W_mean.bias'])
     z_log_var = -torch.abs(F.linear(cond, p['decoder.W_log_var.weight'], p['decoder.W_log_var.bias']))

@@ -74,7 +74,7 @@ BLOB_FIELDS = BATCH_PTRS
 
 class Batch(C.Structure):
     _fields_ = ([(k, i32) for k in ('B', 'n', 'E', 'E_in', 'S', 'L')] + [(k, vp) for k in BATCH_PTRS] +
-                [('props', vp), ('eps', vp), ('denoms', vp)])
+                [('props', vp), ('eps', vp), ('denoms', vp), ('conds', vp), ('d_conds', vp), ('d_z', vp)])
 
 
 _lib = None
@@ -133,7 +133,7 @@ def lib():
     L.psvae_profile_class_name.restype = C.c_char_p
     L.psvae_profile_class_name.argtypes = [C.c_int]
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
-    if L.psvae_abi_version() != 1:
+    if L.psvae_abi_version() != 2:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
     return L

@@ -279,21 +279,26 @@ __global__ void split_mulv_kernel(const float* __restrict__ mulv, float* __restr
 int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, const psvae_batch& b, const Sz& s,
                     const WS& w, bool with_decoder_stack) {
     PSVAE_TRY(embed3_gather(st, b.atom_id, b.piece_id, b.pos_id, p.atom_emb, p.piece_emb, p.pos_emb, s.Da, s.Dp, s.Dq, w.X0, s.n));
+    const float* cond = b.conds ? b.conds : w.cond;
     Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
-    if (with_decoder_stack && s.te == s.td) {
+    if (b.conds) {   // decoder-only: the conditions come from the caller, only the decoder-side stack runs
+        PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1));
+    } else if (with_decoder_stack && s.te == s.td) {
         PSVAE_TRY(stacks_forward(st, s, w, k, 2));
     } else {
         PSVAE_TRY(stacks_forward(st, s, w, &k[0], 1));
         if (with_decoder_stack) PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1));
     }
-    PSVAE_TRY(segment_pool_fwd(st, w.XE + s.H, (s.te + 1) * s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
-    PSVAE_TRY(linear_fwd(st, w.pooled, s.te * s.H, p.enc_lin_w, p.enc_lin_b, w.cond, s.G, s.B, s.G, s.te * s.H, 0,
-                         w.scratch, w.scratch_floats));
+    if (!b.conds) {
+        PSVAE_TRY(segment_pool_fwd(st, w.XE + s.H, (s.te + 1) * s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
+        PSVAE_TRY(linear_fwd(st, w.pooled, s.te * s.H, p.enc_lin_w, p.enc_lin_b, w.cond, s.G, s.B, s.G, s.te * s.H, 0,
+                             w.scratch, w.scratch_floats));
+    }
     if (p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z) {
-        PSVAE_TRY(linear_fwd(st, w.cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, 0, w.scratch, w.scratch_floats));
+        PSVAE_TRY(linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, 0, w.scratch, w.scratch_floats));
     } else {
-        PSVAE_TRY(linear_fwd(st, w.cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
-        PSVAE_TRY(linear_fwd(st, w.cond, s.G, p.lvar_w, p.lvar_b, w.mulv + s.Z, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
+        PSVAE_TRY(linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
+        PSVAE_TRY(linear_fwd(st, cond, s.G, p.lvar_w, p.lvar_b, w.mulv + s.Z, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
     }
     return 0;
 }
@@ -344,10 +349,15 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
     PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
     // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
-    PSVAE_TRY(linear_fwd(s2, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch2, scf));
-    PSVAE_TRY(linear_fwd(s2, w.q1, s.Hp, p.pred_w1, p.pred_b1, w.q2, s.Hp, s.B, s.Hp, s.Hp, 1, w.scratch2, scf));
-    PSVAE_TRY(linear_fwd(s2, w.q2, s.Hp, p.pred_wo, p.pred_bo, w.pred, s.ldpred, s.B, s.NP, s.Hp, 0, w.scratch2, scf));
-    PSVAE_TRY(mse_fwd(s2, w.pred, s.ldpred, b.props, w.mse_row, s.B, s.NP));
+    const bool dec_only = b.conds != nullptr;
+    if (!dec_only) {
+        PSVAE_TRY(linear_fwd(s2, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch2, scf));
+        PSVAE_TRY(linear_fwd(s2, w.q1, s.Hp, p.pred_w1, p.pred_b1, w.q2, s.Hp, s.B, s.Hp, s.Hp, 1, w.scratch2, scf));
+        PSVAE_TRY(linear_fwd(s2, w.q2, s.Hp, p.pred_wo, p.pred_bo, w.pred, s.ldpred, s.B, s.NP, s.Hp, 0, w.scratch2, scf));
+        PSVAE_TRY(mse_fwd(s2, w.pred, s.ldpred, b.props, w.mse_row, s.B, s.NP));
+    } else {
+        PSVAE_TRY(fill_zero(s2, w.mse_row, s.B));   // no property head: its loss reads 0
+    }
     // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
     PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
     PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
@@ -392,14 +402,21 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     PSVAE_TRY(linear_bwd_w(s1, w.dgi, 3 * s.R, 0, w.semb, s.Dp, 0, 1, g.gru_wih, g.gru_bih, s.BT, 3 * s.R, s.Dp, sc1, scf));
     PSVAE_TRY(linear_bwd_w(s1, w.dh0, s.R, 0, w.z, s.Z, 0, 1, g.l2h_w, g.l2h_b, s.B, s.R, s.Z, sc1, scf));
     // --- lane 2: property head
-    PSVAE_TRY(mse_bwd(s2, w.pred, s.ldpred, b.props, gs, b.denoms, w.dpred, s.B, s.NP));
-    PSVAE_TRY(linear_bwd_x(s2, w.dpred, s.ldpred, p.pred_wo, w.dq2, s.Hp, s.B, s.NP, s.Hp, w.q2, s.Hp, 0));
-    PSVAE_TRY(linear_bwd_x(s2, w.dq2, s.Hp, p.pred_w1, w.dq1, s.Hp, s.B, s.Hp, s.Hp, w.q1, s.Hp, 0));
-    PSVAE_TRY(linear_bwd_x(s2, w.dq1, s.Hp, p.pred_w0, w.dz, s.Z, s.B, s.Hp, s.Z, nullptr, 0, 0));
+    const bool dec_only = b.conds != nullptr;
+    if (dec_only && !b.d_conds) return PSVAE_E_NULL;
+    const float* cond = dec_only ? b.conds : w.cond;
+    if (!dec_only) {
+        PSVAE_TRY(mse_bwd(s2, w.pred, s.ldpred, b.props, gs, b.denoms, w.dpred, s.B, s.NP));
+        PSVAE_TRY(linear_bwd_x(s2, w.dpred, s.ldpred, p.pred_wo, w.dq2, s.Hp, s.B, s.NP, s.Hp, w.q2, s.Hp, 0));
+        PSVAE_TRY(linear_bwd_x(s2, w.dq2, s.Hp, p.pred_w1, w.dq1, s.Hp, s.B, s.Hp, s.Hp, w.q1, s.Hp, 0));
+        PSVAE_TRY(linear_bwd_x(s2, w.dq1, s.Hp, p.pred_w0, w.dz, s.Z, s.B, s.Hp, s.Z, nullptr, 0, 0));
+    }
     if (L && hipEventRecord(L->ev[3], s2) != hipSuccess) return (int)hipGetLastError();   // dz (property head part) ready
-    PSVAE_TRY(linear_bwd_w(s2, w.dpred, s.ldpred, 0, w.q2, s.Hp, 0, 1, g.pred_wo, g.pred_bo, s.B, s.NP, s.Hp, sc2, scf));
-    PSVAE_TRY(linear_bwd_w(s2, w.dq2, s.Hp, 0, w.q1, s.Hp, 0, 1, g.pred_w1, g.pred_b1, s.B, s.Hp, s.Hp, sc2, scf));
-    PSVAE_TRY(linear_bwd_w(s2, w.dq1, s.Hp, 0, w.z, s.Z, 0, 1, g.pred_w0, g.pred_b0, s.B, s.Hp, s.Z, sc2, scf));
+    if (!dec_only) {
+        PSVAE_TRY(linear_bwd_w(s2, w.dpred, s.ldpred, 0, w.q2, s.Hp, 0, 1, g.pred_wo, g.pred_bo, s.B, s.NP, s.Hp, sc2, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.dq2, s.Hp, 0, w.q1, s.Hp, 0, 1, g.pred_w1, g.pred_b1, s.B, s.Hp, s.Hp, sc2, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.dq1, s.Hp, 0, w.z, s.Z, 0, 1, g.pred_w0, g.pred_b0, s.B, s.Hp, s.Z, sc2, scf));
+    }
     // --- main: link scorer input-gradient chain; its weight gradients follow on lane 2
     PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
@@ -419,30 +436,36 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     // --- latent head and encoder.linear: needs the three parts of dL/dz
     if (L && (hipStreamWaitEvent(st, L->ev[2], 0) != hipSuccess || hipStreamWaitEvent(st, L->ev[3], 0) != hipSuccess))
         return (int)hipGetLastError();
-    PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz, w.dz_piece, w.dz_pair, gs, b.denoms, w.dmulv, s.B, s.Z));
+    if (dec_only) PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz_piece, w.dz_pair, b.d_z, gs, b.denoms, w.dmulv, s.B, s.Z));
+    else PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz, w.dz_piece, w.dz_pair, gs, b.denoms, w.dmulv, s.B, s.Z));
+    float* dcond = dec_only ? b.d_conds : w.dcond;
     const bool head_adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z &&
                                g.lvar_w == g.mean_w + (size_t)s.Z * s.G && g.lvar_b == g.mean_b + s.Z;
     if (head_adjacent) {
-        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, w.cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc, scf));
-        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, w.dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
     } else {
-        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, w.cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, s.Z, s.G, sc, scf));
-        PSVAE_TRY(linear_bwd_w(st, w.dmulv + s.Z, 2 * s.Z, 0, w.cond, s.G, 0, 1, g.lvar_w, g.lvar_b, s.B, s.Z, s.G, sc, scf));
-        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, w.dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 0));
-        PSVAE_TRY(linear_bwd_x(st, w.dmulv + s.Z, 2 * s.Z, p.lvar_w, w.dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 1));
+        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_w(st, w.dmulv + s.Z, 2 * s.Z, 0, cond, s.G, 0, 1, g.lvar_w, g.lvar_b, s.B, s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_x(st, w.dmulv + s.Z, 2 * s.Z, p.lvar_w, dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 1));
     }
     const int TH = s.te * s.H;
-    PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
-    PSVAE_TRY(linear_bwd_w(st, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc, scf));
+    if (!dec_only) {
+        PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_w(st, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc, scf));
+    }
     // --- GINE stacks: dL/dx_te of the encoder is the broadcast of the last pooled slice
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
-    {
+    if (!dec_only) {
         AggBwdGroup top{nullptr, nullptr, w.GE + (size_t)s.te * nH, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f,
                         w.dpooled + (size_t)(s.te - 1) * s.H, 0, nullptr};
         PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
     }
     const float* dpool[2] = {w.dpooled, nullptr};
-    if (s.te == s.td) {
+    if (dec_only) {
+        PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1, 1));
+    } else if (s.te == s.td) {
         PSVAE_TRY(stacks_backward(st, s, w, b, k, 2, dpool, 0, 0));
     } else {
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0, 0));
@@ -451,7 +474,7 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     // weight gradients of the shared GINE MLPs (sum over the t applications): encoder on lane 1,
     // decoder-side encoder on lane 2, beside node_trans / edge_trans / embedding tables on main
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[8])); PSVAE_TRY(hand_over(st, s2, L->ev[9])); }
-    for (int q = 0; q < 2; ++q) {
+    for (int q = dec_only ? 1 : 0; q < 2; ++q) {
         hipStream_t sq = q == 0 ? s1 : s2;
         float* scq = q == 0 ? sc1 : sc2;
         PSVAE_TRY(linear_bwd_w(sq, k[q].Gr + nH, s.H, (int64_t)nH, k[q].Hid, s.H, (int64_t)nH, k[q].t, k[q].g_w2, k[q].g_b2,
@@ -459,7 +482,9 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
         PSVAE_TRY(linear_bwd_w(sq, k[q].DH, s.H, (int64_t)nH, k[q].A, s.H, (int64_t)nH, k[q].t, k[q].g_w1, k[q].g_b1,
                                s.n, s.H, s.H, scq, scf));
     }
-    if (s.te == s.td) {
+    if (dec_only) {
+        PSVAE_TRY(stacks_edge_grads(st, s, w, &k[1], 1, 1));
+    } else if (s.te == s.td) {
         PSVAE_TRY(stacks_edge_grads(st, s, w, k, 2, 0));
     } else {
         PSVAE_TRY(stacks_edge_grads(st, s, w, &k[0], 1, 0));
@@ -468,7 +493,10 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     // --- node_trans of both stacks from G0 = [dL/dx0_enc | dL/dx0_dec]  ([n, 2H])
     const bool node_adjacent = p.dec_node_w == p.enc_node_w + (size_t)s.H * s.Din && g.dec_node_w == g.enc_node_w + (size_t)s.H * s.Din &&
                                g.dec_node_b == g.enc_node_b + s.H;
-    if (node_adjacent) {
+    if (dec_only) {
+        PSVAE_TRY(linear_bwd_x(st, w.G0 + s.H, 2 * s.H, p.dec_node_w, w.dX0, s.Din, s.n, s.H, s.Din, nullptr, 0, 0));
+        PSVAE_TRY(linear_bwd_w(st, w.G0 + s.H, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.dec_node_w, g.dec_node_b, s.n, s.H, s.Din, sc, scf));
+    } else if (node_adjacent) {
         PSVAE_TRY(linear_bwd_x(st, w.G0, 2 * s.H, p.enc_node_w, w.dX0, s.Din, s.n, 2 * s.H, s.Din, nullptr, 0, 0));
         PSVAE_TRY(linear_bwd_w(st, w.G0, 2 * s.H, 0, w.X0, s.Din, 0, 1, g.enc_node_w, g.enc_node_b, s.n, 2 * s.H, s.Din, sc, scf));
     } else {

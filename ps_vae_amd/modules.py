@@ -157,6 +157,11 @@ class VAEPieceDecoder(nn.Module):
         return torch.cat([self.atom_embedding.weight[atom_ids], self.piece_embedding.weight[piece_ids],
                           self.pos_embedding.weight[pos_ids]], dim=-1)
 
-    def forward(self, *args, **kwargs):
-        raise RuntimeError('VAEPieceDecoder.forward runs as part of the fused step: call PSVAEModel.forward(batch), '
-                           'which owns the packed batch layout the HIP kernels read')
+    def forward(self, x, x_pieces, x_pos, edge_index, edge_attr, pieces, conds, edge_select, golden_edge,
+                return_accu=False, eps=None):
+        """`:71-126`: returns `(z, (rec, piece, edge, kl))`, with `return_accu` `(z, ((...), (piece_accu,
+        edge_accu)))`.  Runs the fused step in decoder-only mode; inside `PSVAEModel.forward` the same
+        kernels run together with the encoder in one call.  `eps` optionally replaces the N(0,1) draw."""
+        from .decoder_step import decoder_forward
+        return decoder_forward(self, x, x_pieces, x_pos, edge_index, edge_attr, pieces, conds, edge_select, golden_edge,
+                               return_accu=return_accu, eps=eps)
