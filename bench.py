@@ -128,17 +128,27 @@ def main():
     cpu_batches, collate_s = make_batches(tok, args.vocab, args.shape, args.batch_size, n_distinct, seed=2021 + rank)
     batches = [to_device(b, dev) for b in cpu_batches]
     model.flat_buffers()
-    reducer = GradReducer(model.bucket_bounds)
+    reducer = GradReducer([0, model._n_trained])     # one collective for the whole gradient (7.6 MB)
     local_denoms = [b['_native'].denoms.clone() for b in batches]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
+    pending = {}
+
+    def exchange_denoms(i):
+        # global loss denominators of batch i: needs only the batch, so it is issued one step ahead
+        if shared_gpu:
+            torch.cuda.synchronize()
+        j = i % n_distinct
+        pending[i] = reducer.reduce_denoms(local_denoms[j], out=batches[j]['_native'].denoms, async_op=True)[1]
+
     def step(i):
         batch = batches[i % n_distinct]
-        nb = batch['_native']
         if world > 1:
-            if shared_gpu:
-                torch.cuda.synchronize()
-            reducer.reduce_denoms(local_denoms[i % n_distinct], out=nb.denoms)
+            if i not in pending:
+                exchange_denoms(i)
+            work = pending.pop(i)
+            if work is not None:
+                work.wait()
         eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
         opt.zero_grad()
         loss = model.training_step(batch, eps=eps)
@@ -149,6 +159,7 @@ def main():
             reducer.reduce_grads(model.flat_buffers()[1])
             if shared_gpu:
                 torch.cuda.synchronize()
+            exchange_denoms(i + 1)
         opt.step()
         model.global_step += 1
         return loss

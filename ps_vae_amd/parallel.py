@@ -25,12 +25,14 @@ def shard_range(n_items, rank, world):
 
 
 class GradReducer:
-    """All-reduce (sum) of a flat gradient buffer in a few large buckets.
+    """All-reduce (sum) of a flat gradient buffer.
 
-    `bounds` are bucket boundaries (element offsets) in the order the buckets
-    become final during backward; each bucket is one collective.  xGMI is a
-    point-to-point mesh and this message is only ~7.6 MB, so the transfer is
-    latency-bound: few big collectives, never per-parameter ones."""
+    `bounds` are bucket boundaries (element offsets); each bucket is one
+    collective.  xGMI is a point-to-point mesh and the whole gradient is only
+    ~7.6 MB, so the transfer is latency-bound: as long as the collectives run
+    after backward (not overlapped with it) ONE bucket `[0, n]` is the fastest
+    choice; `model.bucket_bounds` lists where backward finishes groups of
+    parameters, for callers that overlap."""
 
     def __init__(self, bounds, group=None):
         self.bounds = list(bounds)
@@ -47,12 +49,13 @@ class GradReducer:
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
-    def reduce_denoms(self, local_denoms, out=None):
-        """Global loss denominators: sum of the per-rank counts."""
+    def reduce_denoms(self, local_denoms, out=None, async_op=False):
+        """Global loss denominators: sum of the per-rank counts.  With `async_op` the collective is only
+        enqueued (it depends on nothing but the batch, so it can run a step ahead); the returned handle's
+        `wait()` makes the current stream wait for it.  Returns `out`, or `(out, handle)`."""
         out = local_denoms.clone() if out is None else out.copy_(local_denoms)
-        if self.world > 1:
-            self._all_reduce(out)
-        return out
+        work = self._all_reduce(out, async_op=async_op) if self.world > 1 else None
+        return (out, work) if async_op else out
 
     def reduce_grads(self, flat_grads, async_op=False):
         if self.world == 1:
