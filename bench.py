@@ -84,6 +84,21 @@ def cpu_baseline(cpu_batch, qm9_batch, vocab, budget_s=12.0, max_steps=8):
                         'sample': f'{nq} steps on one batch of {Bq} QM9-shape graphs ({dtq / nq * 1e3:.1f} ms/step)'}}
 
 
+PMC_FILE = 'profiles/r01_pmc_traffic.json'
+
+
+def pmc_traffic(kernel_class, args):
+    """HBM-side bytes per launch of a kernel class, measured beforehand with rocprofv3 PMC passes of this
+    same command (tools/pmc_traffic.py wrote the summary); None when no measurement of this workload exists."""
+    if (args.shape, args.vocab, args.batch_size) != ('zinc', 300, 128):
+        return None
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f)['classes'][kernel_class]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,7 +233,10 @@ def main():
     else:
         achieved, peak, unit, bound = dwork / (dms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s', 'hbm'
     roofline = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
-                'traffic': None, 'avg_launch_us': dms / dcnt * 1e3, 'launches_per_step': dcnt / args.profile_steps}
+                'traffic': pmc_traffic(dom, args), 'traffic_unit': 'HBM-side bytes per launch (rocprofv3 PMC, see traffic_source)',
+                'traffic_source': PMC_FILE if pmc_traffic(dom, args) is not None else None,
+                'algorithmic_per_launch': dwork / dcnt, 'avg_launch_us': dms / dcnt * 1e3,
+                'launches_per_step': dcnt / args.profile_steps}
     mp = [k for k in ('gine_aggregate_fwd', 'gine_aggregate_bwd') if k in classes]
     mp_ms = sum(classes[k][0] for k in mp)
     mp_bytes = sum(classes[k][1] for k in mp)
