@@ -1,0 +1,71 @@
+"""The C ABI without a GPU: libpsvae_hip.so loads, exports every function include/psvae.h declares,
+the ctypes mirrors of its structs have the header's field counts, argument errors are reported by
+code before anything is launched, and the product path refuses to run without a GPU instead of
+falling back to anything else."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from ps_vae_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, 'include', 'psvae.h')).read()
+
+
+def declared_functions():
+    body = re.sub(r'/\*.*?\*/', '', HEADER, flags=re.S)
+    return sorted(set(re.findall(r'\b(psvae_[a-z0-9_]+)\s*\(', body)))
+
+
+def struct_fields(name):
+    body = re.sub(r'/\*.*?\*/', '', HEADER, flags=re.S)
+    block = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), body, flags=re.S).group(1)
+    n = 0
+    for decl in block.split(';'):
+        decl = decl.strip()
+        if decl:
+            n += decl.count(',') + 1
+    return n
+
+
+def test_library_exports_every_declared_function():
+    L = _lib.lib()
+    names = declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == names, set(names) ^ set(_lib.EXPORTS)
+    assert L.psvae_abi_version() == int(re.search(r'#define PSVAE_ABI_VERSION (\d+)', HEADER).group(1))
+
+
+def test_ctypes_structs_mirror_the_header():
+    assert len(_lib.Dims._fields_) == struct_fields('psvae_dims')
+    assert len(_lib.Params._fields_) == struct_fields('psvae_params')
+    assert len(_lib.Batch._fields_) == struct_fields('psvae_batch')
+    assert C.sizeof(_lib.Params) == 8 * len(_lib.Params._fields_)
+    assert len(_lib.BLOB_FIELDS) == len(re.findall(r'PSVAE_BLOB_[A-Z_]+', HEADER.split('enum {')[-1].split('}')[0])) - 1
+
+
+def test_argument_errors_come_back_as_codes():
+    L = _lib.lib()
+    assert L.psvae_strerror(0) and L.psvae_strerror(-1) != L.psvae_strerror(-2)
+    assert L.psvae_linear_forward(None, 4, None, None, None, 4, 8, 4, 4, 0, None, 0, None) == -1          # PSVAE_E_NULL
+    assert L.psvae_gru_forward(None, None, None, None, None, None, None, 4, 2, 8, None, 0, None) == -1
+    dims, batch = _lib.Dims(), _lib.Batch()
+    assert L.psvae_workspace_bytes(C.byref(dims), C.byref(batch)) == 0                                    # rejected sizes
+    assert L.psvae_step_forward(C.byref(dims), None, C.byref(batch), None, 0, None, None, None) < 0
+    with pytest.raises(RuntimeError):
+        _lib.check(-2, 'probe')
+
+
+def test_no_cpu_path():
+    """Without a GPU the model raises: there is no CPU implementation behind the module surface."""
+    from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config
+    tok = Tokenizer.synthetic(30)
+    model = PSVAEModel(full_config(default_args(), tok), tok)
+    assert len(model.state_dict()) == 51
+    with pytest.raises(RuntimeError, match='GPU'):
+        model({'x': torch.zeros(1, 1, dtype=torch.long)})
