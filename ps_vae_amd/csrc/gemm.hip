@@ -14,6 +14,7 @@
 // K-steps ahead into two named register stages (global -> VGPR -> LDS), which
 // keeps ~2 x 16 MFMAs of work between a load's issue and its first use.
 #include "psvae_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -259,14 +260,15 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
     }
 }
 
-// Reduction split: aim for ~4 workgroups per CU (occupancy hides the load latency of
+// Reduction split: aim for ~2 workgroups per CU (PSVAE_SPLIT_TARGET overrides the 512 target) (occupancy hides the load latency of
 // these short K loops) while keeping at least 4 K-steps per workgroup.
 struct Plan { int splits, rchunk; };
 Plan plan_splits(int M, int N, int R, int nseg) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nseg;
     Plan pl{1, (int)round_up(R > 0 ? R : 1, BK)};
     if (tiles >= 200 || R <= 4 * BK) return pl;
-    int want = (int)((1024 + tiles - 1) / tiles);
+    static const int target = [] { const char* e = getenv("PSVAE_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    int want = (int)((target + tiles - 1) / tiles);
     int maxs = R / (4 * BK);
     if (want > maxs) want = maxs;
     if (want <= 1) return pl;

@@ -343,6 +343,14 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true));
     PSVAE_TRY(vae_head_fwd(st, w.mulv, b.eps, w.z, w.klrow, s.B, s.Z));
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[1])); PSVAE_TRY(hand_over(st, s2, L->ev[2])); }
+    // (the scorer, the longest of the three branches, is queued first)
+    // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
+    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
+    PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
+    PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
     // lane 1: GRU + vocabulary logits + piece loss rows
     PSVAE_TRY(linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, 0, w.scratch1, scf));
     PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes));
@@ -358,13 +366,6 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     } else {
         PSVAE_TRY(fill_zero(s2, w.mse_row, s.B));   // no property head: its loss reads 0
     }
-    // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
-    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
-    PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
-    PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
-    PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));
-    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
-    PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
     if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[3])); PSVAE_TRY(hand_over(s2, st, L->ev[4])); }
     PSVAE_TRY(losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, w.losses));
     if (hipMemcpyAsync(losses, w.losses, 6 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
