@@ -183,6 +183,9 @@ int psvae_profile_enable(int on);
 int psvae_profile_num_classes(void);
 const char* psvae_profile_class_name(int kernel_class);
 int psvae_profile_collect(double* ms, double* work, int64_t* launches);
+/* Median time (ms) a hipEvent pair measures around an EMPTY kernel on `stream` (64 samples; synchronises the
+ * stream): what the bracketing itself adds to every duration above.  Negative on failure. */
+double psvae_profile_event_overhead_ms(void* stream);
 
 /* ---- single operators (same kernels as the step; used by the module-level API
  * and the per-layer parity tests) -------------------------------------------- */

@@ -133,6 +133,8 @@ def lib():
     L.psvae_profile_class_name.restype = C.c_char_p
     L.psvae_profile_class_name.argtypes = [C.c_int]
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
+    L.psvae_profile_event_overhead_ms.restype = C.c_double
+    L.psvae_profile_event_overhead_ms.argtypes = [vp]
     if L.psvae_abi_version() != 2:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
@@ -147,7 +149,7 @@ EXPORTS = (
     'psvae_segment_pool_forward',
     'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
     'psvae_pack_bound', 'psvae_pack_batch', 'psvae_profile_enable', 'psvae_profile_num_classes',
-    'psvae_profile_class_name', 'psvae_profile_collect')
+    'psvae_profile_class_name', 'psvae_profile_collect', 'psvae_profile_event_overhead_ms')
 
 
 def profile_collect():

@@ -5,6 +5,7 @@
 // thread-safe, and the only global state the library has.
 #include "psvae_internal.h"
 #include <vector>
+#include <algorithm>
 
 namespace {
 struct Rec { int kc; double work; hipEvent_t a, b; };
@@ -59,4 +60,30 @@ extern "C" int psvae_profile_collect(double* ms, double* work, int64_t* launches
     }
     g_recs.clear();
     return 0;
+}
+
+namespace {
+__global__ void profile_empty_kernel() {}
+}
+
+// What a hipEvent pair adds around a launch: the median time between the two events around an empty
+// kernel, in ms (64 samples on `stream`, which is synchronised).  Subtract it per launch from
+// psvae_profile_collect's durations to compare with a profiler's kernel-only durations.
+extern "C" double psvae_profile_event_overhead_ms(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> t;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
+    for (int i = 0; i < 72; ++i) {
+        (void)hipEventRecord(a, s);
+        hipLaunchKernelGGL(profile_empty_kernel, dim3(256), dim3(256), 0, s);
+        (void)hipEventRecord(b, s);
+        if (hipEventSynchronize(b) != hipSuccess) return -1.0;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0;
+        if (i >= 8) t.push_back(ms);
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
 }
