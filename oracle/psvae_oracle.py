@@ -321,3 +321,41 @@ class Trainer:
         self.opt.step()
         self.step_idx += 1
         return float(total.detach()), {k: float(v.detach()) for k, v in losses.items()}
+
+
+def direct_optimize(p, d, z, target, lr, max_iter, patience, selected=(0, 2)):
+    """`direct_optimize` (`src/generate.py:67-89`) with `get_loss` (`:30-44`) and the padding of
+    `predict_props` (`ps_vae_model.py:146-153`) for ONE latent vector `z` [latent]."""
+    def predict_props(zz):
+        q = torch.relu(F.linear(zz, p['predictor.mlp.0.weight'], p['predictor.mlp.0.bias']))
+        q = torch.relu(F.linear(q, p['predictor.mlp.2.weight'], p['predictor.mlp.2.bias']))
+        props = F.linear(q, p['predictor.output.weight'], p['predictor.output.bias'])
+        padded = [torch.tensor(0.0) for _ in range(3)]
+        for i, val in zip(selected, props):
+            padded[i] = val
+        return torch.stack(padded)
+
+    def get_loss(props):
+        tar = torch.tensor([v for v in target if v is not None], dtype=torch.float)
+        idx = torch.tensor([i for i, v in enumerate(target) if v is not None], dtype=torch.long)
+        return F.mse_loss(torch.index_select(props, 0, idx), tar)
+
+    optimized = z.clone()
+    optimized.requires_grad = True
+    opt = torch.optim.Adam([optimized], lr=lr)
+    best_loss, not_inc, best_z = 100, 0, optimized.clone()
+    steps = 0
+    for _ in range(max_iter):
+        loss = get_loss(predict_props(optimized))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        steps += 1
+        loss = loss.item()
+        if loss < best_loss:
+            best_loss, not_inc, best_z = loss, 0, optimized.clone()
+        else:
+            not_inc += 1
+            if not_inc > patience:
+                break
+    return best_z.detach(), best_loss, steps
