@@ -277,6 +277,17 @@ class PSVAEModel(nn.Module):
         self.forward(batch, eps=eps)
         return self._last_total
 
+    def validation_step(self, batch, batch_idx=0, eps=None):
+        """`ps_vae_model.py:90-96`: weighted loss and the two accuracies of one batch."""
+        pred_loss, (losses, accus) = self.forward(batch, return_accu=True, eps=eps)
+        return {'val_loss': self.weighted_loss(pred_loss, losses[0], losses[-1]).detach(),
+                'piece accu': accus[0], 'edge accu': accus[1]}
+
+    def test_step(self, batch, batch_idx=0, eps=None):
+        """`ps_vae_model.py:118-121`."""
+        pred_loss, losses = self.forward(batch, eps=eps)
+        return {'test_loss': self.weighted_loss(pred_loss, losses[0], losses[-1]).detach()}
+
     def configure_optimizers(self):
         from .optim import FusedClipAdam
         return FusedClipAdam(self, lr=self.config['lr'])

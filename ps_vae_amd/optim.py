@@ -27,9 +27,10 @@ class FusedClipAdam:
 
     def _state(self, params):
         if self.exp_avg is None or self.exp_avg.device != params.device or self.exp_avg.numel() != params.numel():
-            L = _lib.lib()
             self.exp_avg = torch.zeros_like(params)
             self.exp_avg_sq = torch.zeros_like(params)
+        if self.partials is None or self.partials.device != params.device:      # also after load_state_dict
+            L = _lib.lib()
             self.partials = torch.zeros(L.psvae_adam_partials(params.numel()), dtype=torch.float32, device=params.device)
             self.grad_norm = torch.zeros(1, dtype=torch.float32, device=params.device)
 

@@ -1,0 +1,123 @@
+"""What PyTorch Lightning drives for the reference (`src/train.py:32-58`): the epoch loop with
+validation, checkpointing on the monitored value, and the KL-warm-up-aware early stopping
+(`src/utils/nn_utils.py:126-136`), plus checkpoint files in Lightning's layout
+(`state_dict`, `epoch`, `global_step`, `optimizer_states`, `hyper_parameters`) that hold tensors
+and plain containers only, so `torch.load(..., weights_only=True)` reads them."""
+import math
+import os
+
+import torch
+
+from .data import to_device
+
+
+class VAEEarlyStopping:
+    """`VAEEarlyStopping` (`src/utils/nn_utils.py:126-136`) on top of Lightning's `EarlyStopping(monitor,
+    patience, mode='min', min_delta=0)`: stop when the monitored value has not improved for `patience`
+    validations, but keep resetting the record while `global_step < finish_anneal_step` (the loss is still
+    being re-weighted by the KL schedule)."""
+
+    def __init__(self, finish_anneal_step, patience=3, min_delta=0.0):
+        self.finish_anneal_step, self.patience, self.min_delta = finish_anneal_step, patience, min_delta
+        self.best_score, self.wait_count = math.inf, 0
+
+    def on_validation_end(self, monitored, global_step):
+        """Returns True when training should stop."""
+        stop = False
+        if monitored < self.best_score - self.min_delta:
+            self.best_score, self.wait_count = monitored, 0
+        else:
+            self.wait_count += 1
+            stop = self.wait_count >= self.patience
+        if global_step < self.finish_anneal_step:
+            self.best_score, self.wait_count = math.inf, 0
+        return stop
+
+
+def finish_anneal_step(config):
+    """`src/train.py:37`: the step at which beta reaches its maximum."""
+    return config['kl_warmup'] + (config['max_beta'] // config['step_beta'] - 1) * config['kl_anneal_iter']
+
+
+def _plain(obj):
+    """Config values as plain Python containers (what a weights-only load accepts)."""
+    if isinstance(obj, dict):
+        return {str(k): _plain(v) for k, v in obj.items() if _is_plain(v)}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj if _is_plain(v)]
+    return obj
+
+
+def _is_plain(v):
+    return isinstance(v, (bool, int, float, str, type(None), dict, list, tuple))
+
+
+def save_checkpoint(path, model, optimizer, epoch):
+    opt = optimizer.state_dict()
+    ckpt = {
+        'epoch': int(epoch), 'global_step': int(model.global_step),
+        'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
+        'optimizer_states': [{'step': int(opt['step']), 'epoch': int(opt['epoch']),
+                              'exp_avg': None if opt['exp_avg'] is None else opt['exp_avg'].detach().cpu(),
+                              'exp_avg_sq': None if opt['exp_avg_sq'] is None else opt['exp_avg_sq'].detach().cpu()}],
+        'hyper_parameters': {'config': _plain(model.config)},
+    }
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(ckpt, path)
+
+
+def load_checkpoint(path, model, optimizer=None):
+    """Restores a checkpoint written by `save_checkpoint`, or the `state_dict` of a reference (Lightning)
+    checkpoint.  Only a weights-only load is attempted: a reference `.ckpt` also pickles its tokenizer and
+    config objects, which such a load refuses — export its `state_dict` with the reference code base first."""
+    ckpt = torch.load(path, map_location='cpu', weights_only=True)
+    model.load_state_dict(ckpt['state_dict'])
+    model.global_step = int(ckpt.get('global_step', 0))
+    if optimizer is not None and ckpt.get('optimizer_states'):
+        st = ckpt['optimizer_states'][0]
+        dev = model.flat_buffers()[0].device
+        optimizer.load_state_dict({'step': st['step'], 'epoch': st['epoch'],
+                                   'exp_avg': None if st['exp_avg'] is None else st['exp_avg'].to(dev),
+                                   'exp_avg_sq': None if st['exp_avg_sq'] is None else st['exp_avg_sq'].to(dev)})
+    return int(ckpt.get('epoch', 0))
+
+
+def validate(model, loader, device):
+    """Mean of `validation_step` over a loader (`ps_vae_model.py:90-96`)."""
+    tot = {'val_loss': 0.0, 'piece accu': 0.0, 'edge accu': 0.0}
+    n = 0
+    with torch.no_grad():
+        for batch in loader:
+            out = model.validation_step(to_device(batch, device))
+            for k in tot:
+                tot[k] += float(out[k])
+            n += 1
+    return {k: v / max(n, 1) for k, v in tot.items()}
+
+
+def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3, device='cuda', log=None):
+    """Epoch loop of `trainer.fit` as the reference configures it: Adam with lr / (epoch + 1), clip 10 (both in
+    `configure_optimizers()`'s fused optimiser), validation after every epoch, best-`val_loss` checkpoint,
+    KL-aware early stopping.  Returns the per-epoch validation records."""
+    opt = model.configure_optimizers()
+    stopper = VAEEarlyStopping(finish_anneal_step(model.config), patience=patience)
+    history, best = [], math.inf
+    for epoch in range(max_epochs):
+        opt.set_epoch(epoch)
+        for batch in train_loader:
+            opt.zero_grad()
+            loss = model.training_step(to_device(batch, device))
+            loss.backward()
+            opt.step()
+            model.global_step += 1
+        rec = validate(model, valid_loader, device)
+        rec.update(epoch=epoch, global_step=model.global_step)
+        history.append(rec)
+        if log:
+            log(rec)
+        if save_dir is not None and rec['val_loss'] < best:
+            best = rec['val_loss']
+            save_checkpoint(os.path.join(save_dir, 'best.ckpt'), model, opt, epoch)
+        if stopper.on_validation_end(rec['val_loss'], model.global_step):
+            break
+    return history
