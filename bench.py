@@ -198,6 +198,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
+    if model.recurrence_gave_up():
+        raise SystemExit('the multi-CU GRU recurrence timed out during the run: results are invalid')
 
     # roofline pass: same steps with every launch bracketed by HIP events on its stream
     L = _lib.lib()

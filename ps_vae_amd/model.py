@@ -255,6 +255,17 @@ class PSVAEModel(nn.Module):
         edge_accu = (pair_logits.argmax(-1) == golden).sum().item() / max(S, 1)
         return piece_accu, edge_accu
 
+    def recurrence_gave_up(self):
+        """True if a workgroup of the multi-CU GRU recurrence of the most recent step stopped waiting for its
+        partners (its waits are bounded so that a GPU that cannot keep the group resident cannot hang the
+        process; the step's results are then meaningless).  Synchronises the device."""
+        if self._last_ws is None:
+            return False
+        ws, nb = self._last_ws
+        off = _lib.lib().psvae_workspace_offset(C.byref(self._dims), C.byref(nb.struct()), b'gru_exchange')
+        torch.cuda.synchronize()
+        return bool(ws.view(torch.int32)[off].item() != 0)
+
     def activation(self, name, rows, cols, ld=None):
         """View of a saved activation of the most recent forward (tests, debugging)."""
         return self._ws_view(name, rows, cols, ld)
