@@ -162,6 +162,36 @@ int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_batch* batch_
 int psvae_encode(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
                  void* workspace, size_t workspace_bytes, float* z_mean, float* z_log_var, void* stream);
 
+/* ---- batched front half of generation: the two GPU-shaped stages of
+ * VAEPieceDecoder.inference (src/modules/vae_piece_decoder.py:128-241) for many latents at once.
+ * Turning piece ids into atoms and assembling the molecule (RDKit) stays with the caller.
+ *
+ * psvae_sample_pieces (:134-158): for each of the Bz latents z [Bz, latent] sample the piece sequence from the
+ *   GRU: start token <s>, h0 = latent_to_rnn_hidden(z); every step masks <pad> (and <s> while the
+ *   sequence is empty), draws from softmax(logits / temperature), adds piece_atoms[id] (DEVICE int32
+ *   [num_piece]: atoms of each piece, 0 for <pad> and <s>) to the atom count, and stops on <s>, when the
+ *   count exceeds max_atom_num or at max_pos pieces; the last token drawn is dropped in all three cases.
+ *   The draw of sequence b at step t is the class whose cumulative-probability interval (classes in
+ *   index order) holds uniforms[b*max_pos + t] in [0,1) (DEVICE float [Bz, max_pos]): the caller owns
+ *   the random stream (torch.multinomial's own stream cannot be reproduced).
+ *   piece_ids [Bz, max_pos] int32 receives the tokens (entries at and after lengths[b] are
+ *   unspecified), lengths [Bz] the kept count.  check_every > 0: every that many steps the number of
+ *   running sequences is copied to the host (this SYNCHRONISES the stream) and the loop ends early when
+ *   it is 0; 0 = always max_pos steps, no synchronisation.
+ * psvae_score_links (:203-238): `batch` holds the fragments (atoms, piece/position ids, in-piece bonds as
+ *   in_rowptr/in_col/in_etype) and the candidate pairs; runs embed_atom, the decoder-side GINE stack and the
+ *   scorer, then softmax over the 4 bond classes.  z [B, latent].  Outputs per pair (any may be NULL):
+ *   probs [S,4], confidence [S] = max probability, bond_type [S] = its class (lowest index on ties).
+ *   Workspace: psvae_workspace_bytes(dims, batch). */
+size_t psvae_sample_pieces_workspace_bytes(const psvae_dims* dims, int Bz);
+int psvae_sample_pieces(const psvae_dims* dims, const psvae_params* params, const float* z, int Bz,
+                        const int32_t* piece_atoms, int max_atom_num, float temperature, const float* uniforms,
+                        int32_t* piece_ids, int32_t* lengths, int check_every, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int psvae_score_links(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, const float* z,
+                      void* workspace, size_t workspace_bytes, float* probs, float* confidence, int32_t* bond_type,
+                      void* stream);
+
 /* ---- optimiser: clip_grad_norm_(10) + Adam (src/train.py:47; ps_vae_model.py:123-127)
  * over flat fp32 buffers of `count` elements.  `partials` is scratch of
  * psvae_adam_partials(count) floats; grad_norm_out (device, may be NULL) gets

@@ -359,3 +359,74 @@ def direct_optimize(p, d, z, target, lr, max_iter, patience, selected=(0, 2)):
             if not_inc > patience:
                 break
     return best_z.detach(), best_loss, steps
+
+
+def sample_pieces(p, d, z, piece_atoms, max_atom_num, temperature, uniforms):
+    """The piece-sampling loop of `VAEPieceDecoder.inference` (`src/modules/vae_piece_decoder.py:134-158`)
+    for ONE latent `z` [latent].  `torch.multinomial` (:149) is replaced by inversion of the cumulative
+    distribution at `uniforms[step]` (its own random stream is not reproducible outside torch);
+    everything else follows the loop line by line.  Parity of this loop is unpinned: the reference's
+    `inference` imports RDKit and cannot run here; the GRU cell and `to_vocab` it uses are the ones the
+    golden fixtures pin through the training step."""
+    pad_idx, end_idx = d['num_piece'] - 2, d['num_piece'] - 1
+    emb = p['decoder.piece_embedding.weight']
+    cur = emb[end_idx].view(1, 1, -1)
+    hidden = F.linear(z.view(1, -1), p['decoder.latent_to_rnn_hidden.weight'], p['decoder.latent_to_rnn_hidden.bias'])
+    piece_ids, cur_id, atom_num = [], None, 0
+    while cur_id != end_idx:
+        hidden = gru_sequence(cur, hidden, p)[:, 0]
+        output = F.linear(hidden, p['decoder.to_vocab.weight'], p['decoder.to_vocab.bias']).squeeze().clone()
+        output[pad_idx] = float('-inf')
+        if len(piece_ids) == 0:
+            output[end_idx] = float('-inf')
+        probs = torch.softmax(output / temperature, dim=-1)
+        cdf = torch.cumsum(probs.double(), dim=0)
+        target = float(uniforms[len(piece_ids)]) * float(cdf[-1])
+        cur_id = int(torch.searchsorted(cdf, torch.tensor(target, dtype=torch.double), right=True))
+        cur_id = min(cur_id, d['num_piece'] - 1)
+        cur = emb[cur_id].view(1, 1, -1)
+        atom_num += piece_atoms[cur_id]
+        piece_ids.append(cur_id)
+        if atom_num > max_atom_num:
+            break
+        if len(piece_ids) == d['max_pos']:
+            break
+    return piece_ids[:-1]
+
+
+def score_links(p, d, z, x, x_pieces, x_pos, edge_index, edge_attr, groups):
+    """The link-scoring part of `VAEPieceDecoder.inference` (`src/modules/vae_piece_decoder.py:203-238`) for
+    ONE set of fragments: `edge_index` [[a, b], ...] holds the in-piece bonds in both directions in the
+    order the loop appends them (:189-196), `edge_attr` their bond types.  Returns
+    (pred_edge_index [E,2], softmax(pred_edge) [E,4])."""
+    z = z.view(1, -1)
+    node_x = torch.cat([p['decoder.atom_embedding.weight'][torch.tensor(x, dtype=torch.long)],
+                        p['decoder.piece_embedding.weight'][torch.tensor(x_pieces, dtype=torch.long)],
+                        p['decoder.pos_embedding.weight'][torch.tensor(x_pos, dtype=torch.long)]], dim=-1)
+    if len(edge_index) == 0:
+        ei = torch.zeros(2, 0, dtype=torch.long)
+    else:
+        ei = torch.tensor(edge_index, dtype=torch.long).t().contiguous()
+    ea = F.one_hot(torch.tensor(edge_attr, dtype=torch.long), num_classes=d['num_bond'])
+    node_embedding = embed_node(node_x, ei, ea, p, 'decoder.graph_embedding.', d['t_dec'])[-1]
+    n = len(x)
+    edge_select = torch.triu(torch.ones(n, n, dtype=torch.long))
+    for group in groups:
+        for i in range(len(group)):
+            for j in range(i, len(group)):
+                m, k = group[i], group[j]
+                edge_select[m][k] = edge_select[k][m] = 0
+    edge_select = edge_select.unsqueeze(0).bool()
+    node_embedding = node_embedding.unsqueeze(0)
+    src = torch.repeat_interleave(node_embedding, n, dim=1).view(1, n, n, -1)[edge_select]
+    dst = torch.repeat_interleave(node_embedding, n, dim=0).view(1, n, n, -1)[edge_select]
+    lat = torch.repeat_interleave(z, n ** 2, dim=0).view(1, n, n, -1)[edge_select]
+    h = torch.cat([src, dst, lat], dim=-1)
+    pred_edge_index = torch.nonzero(edge_select.squeeze(0))
+    if h.shape[0] == 0:
+        return pred_edge_index, torch.zeros(0, d['num_bond'])
+    for k in (0, 2):
+        h = torch.relu(F.linear(h, p[f'decoder.edge_predictor.0.seq.{k}.weight'], p[f'decoder.edge_predictor.0.seq.{k}.bias']))
+    h = F.linear(h, p['decoder.edge_predictor.0.seq.4.weight'], p['decoder.edge_predictor.0.seq.4.bias'])
+    pred_edge = F.linear(h, p['decoder.edge_predictor.1.weight'], p['decoder.edge_predictor.1.bias'])
+    return pred_edge_index, torch.softmax(pred_edge, dim=-1)

@@ -102,6 +102,10 @@ def lib():
     L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp]
     L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp]
     L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
+    L.psvae_sample_pieces_workspace_bytes.restype = sz
+    L.psvae_sample_pieces_workspace_bytes.argtypes = [P(Dims), C.c_int]
+    L.psvae_sample_pieces.argtypes = [P(Dims), P(Params), vp, C.c_int, vp, C.c_int, f32, vp, vp, vp, C.c_int, vp, sz, vp]
+    L.psvae_score_links.argtypes = [P(Dims), P(Params), P(Batch), vp, vp, sz, vp, vp, vp, vp]
     L.psvae_adam_partials.restype = sz
     L.psvae_adam_partials.argtypes = [i64]
     L.psvae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]
@@ -143,7 +147,8 @@ def lib():
 
 EXPORTS = (
     'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward',
-    'psvae_step_backward', 'psvae_encode', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
+    'psvae_step_backward', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
+    'psvae_score_links', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',

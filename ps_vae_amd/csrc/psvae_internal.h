@@ -130,6 +130,8 @@ int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* pie
                     const float* edge_row, int S, const float* klrow, const float* denoms, const float* w3, float* losses);
 int make_gscale(hipStream_t s, const float* g6, const float* w3, float* out4);
 int fill_zero(hipStream_t s, float* p, int64_t count);
+// softmax over the 4 bond classes of S pairs: probabilities [S,4], the largest one and its class (any may be null)
+int link_softmax(hipStream_t s, const float* logits, float* probs, float* conf, int32_t* type, int S);
 
 // ------------------------------------------------------------ GRU
 // `exch` (gru_exchange_bytes, 16-byte aligned, or NULL) enables the multi-CU recurrence

@@ -530,3 +530,29 @@ extern "C" int psvae_encode(const psvae_dims* dims, const psvae_params* params, 
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
+
+// Link scores of assembled fragments (src/modules/vae_piece_decoder.py:203-238): atom embeddings, the
+// decoder-side GINE stack over the in-piece bonds, then the scorer over the batch's candidate pairs.
+extern "C" int psvae_score_links(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                                 const float* z, void* workspace, size_t workspace_bytes, float* probs, float* confidence,
+                                 int32_t* bond_type, void* stream) {
+    PSVAE_TRY(check_dims(dims, batch));
+    if (!params || !workspace || !z) return PSVAE_E_NULL;
+    if (!aligned16(workspace) || !aligned16(z) || (probs && !aligned16(probs))) return PSVAE_E_ALIGN;
+    const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_batch& b = *batch;
+    const Sz s = sizes(d, b);
+    WS w;
+    if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t scf = w.scratch_floats;
+    PSVAE_TRY(embed3_gather(st, b.atom_id, b.piece_id, b.pos_id, p.atom_emb, p.piece_emb, p.pos_emb, s.Da, s.Dp, s.Dq, w.X0, s.n));
+    const Stack k = dec_stack(d, p, nullptr, b, w);
+    PSVAE_TRY(stacks_forward(st, s, w, &k, 1));
+    if (s.S == 0) return 0;
+    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
+    PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));
+    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
+    return link_softmax(st, w.slog, probs, confidence, bond_type, s.S);
+}
