@@ -187,9 +187,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()       # per-step spread (median, p10, p90); the headline stays total time / steps
     host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
     fence()
     elapsed = time.perf_counter() - t0
@@ -198,6 +201,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    spread = {'median': per_step[len(per_step) // 2], 'p10': per_step[int(0.1 * (len(per_step) - 1))],
+              'p90': per_step[int(0.9 * (len(per_step) - 1))]}
     if model.recurrence_gave_up():
         raise SystemExit('the multi-CU GRU recurrence timed out during the run: results are invalid')
 
@@ -250,7 +256,7 @@ def main():
     out = {
         'metric': 'train molecules/sec (enc+dec fwd+bwd), ZINC-shape', 'value': value, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'step_ms': spread, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'ZINC250K-shape training step, vocab {args.vocab}, hidden 300, batch {args.batch_size} per GPU '
                                f'(fwd + bwd + clip + Adam{f" + grad all-reduce over {comm}" if world > 1 else ""})',
                    'global_batch': world * args.batch_size, 'parallelism': f'dp{world}', 'params': int(model._n_trained),

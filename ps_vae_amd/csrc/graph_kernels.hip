@@ -8,6 +8,7 @@
 // is a coalesced 16-byte-per-lane stream; neighbour rows of a molecule lie
 // within a few KB of each other and are served by L1/L2.
 #include "psvae_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -15,55 +16,65 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// Edge term of 4 consecutive channels for each of the 4 bond types:
-// e[type][k] = edge_w[(c+k)*4 + type] + edge_b[c+k]   (edge_trans applied to a one-hot)
-struct EdgeTab { float4 t0, t1, t2, t3; };
-__device__ __forceinline__ EdgeTab load_edge_tab(const float* __restrict__ w, const float* __restrict__ b, int c) {
-    const float4 w0 = ld4(w + (long long)c * 4), w1 = ld4(w + (long long)(c + 1) * 4);
-    const float4 w2 = ld4(w + (long long)(c + 2) * 4), w3 = ld4(w + (long long)(c + 3) * 4);
-    const float4 bb = ld4(b + c);
-    EdgeTab e;
-    e.t0 = make_float4(w0.x + bb.x, w1.x + bb.y, w2.x + bb.z, w3.x + bb.w);
-    e.t1 = make_float4(w0.y + bb.x, w1.y + bb.y, w2.y + bb.z, w3.y + bb.w);
-    e.t2 = make_float4(w0.z + bb.x, w1.z + bb.y, w2.z + bb.z, w3.z + bb.w);
-    e.t3 = make_float4(w0.w + bb.x, w1.w + bb.y, w2.w + bb.z, w3.w + bb.w);
-    return e;
-}
-__device__ __forceinline__ float4 pick(const EdgeTab& e, int ty) {
-    return ty == 1 ? e.t1 : (ty == 2 ? e.t2 : (ty == 3 ? e.t3 : e.t0));
+// Edge term e[type][channel] = edge_w[channel*4 + type] + edge_b[channel] (edge_trans applied to a one-hot),
+// staged in LDS: the block reads edge_w [H,4] and edge_b once, as coalesced rows, and leaves the 4 rows in
+// `tab` (4*H floats); a thread then reads the 4 channels of an edge's type with one 16-byte LDS load.
+// (Read straight from global memory, the [H,4] layout costs each wave four 64-byte-strided loads plus a
+// chain of selects per edge, which made the aggregation kernels instruction-bound.)
+__device__ __forceinline__ void stage_edge_tab(float* tab, const float* __restrict__ w, const float* __restrict__ b, int H) {
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const float4 wk = ld4(w + (long long)k * 4);
+        const float bk = b[k];
+        tab[k] = wk.x + bk; tab[H + k] = wk.y + bk; tab[2 * H + k] = wk.z + bk; tab[3 * H + k] = wk.w + bk;
+    }
+    __syncthreads();
 }
 
 struct AggArgs { AggGroup g[2]; int ldx, ldo, n, H4; };
+constexpr int AGG_FWD_MAX_BLOCKS = 1024;   // per group: 4 blocks per CU; larger inputs loop
 
 __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float etab_lds[];
     const AggGroup& g = a.g[blockIdx.y];
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)a.n * a.H4) return;
-    const int i = (int)(t / a.H4), c = (int)(t - (long long)i * a.H4) * 4;
-    const EdgeTab et = load_edge_tab(g.edge_w, g.edge_b, c);
-    const float4 xi = ld4(g.x + (long long)i * a.ldx + c);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int e1 = g.rowptr[i + 1];
-    // neighbours in groups of 4: all index loads, then all row loads, are issued together
-    // (one latency round trip per group instead of per edge); the sum keeps edge order.
-    for (int e = g.rowptr[i]; e < e1; e += 4) {
-        const int m = e1 - e;
-        const int j0 = g.col[e], j1 = m > 1 ? g.col[e + 1] : j0, j2 = m > 2 ? g.col[e + 2] : j0, j3 = m > 3 ? g.col[e + 3] : j0;
-        const int t0 = g.etype[e], t1 = m > 1 ? g.etype[e + 1] : 0, t2 = m > 2 ? g.etype[e + 2] : 0, t3 = m > 3 ? g.etype[e + 3] : 0;
-        const float4 x0 = ld4(g.x + (long long)j0 * a.ldx + c), x1 = ld4(g.x + (long long)j1 * a.ldx + c);
-        const float4 x2 = ld4(g.x + (long long)j2 * a.ldx + c), x3 = ld4(g.x + (long long)j3 * a.ldx + c);
-        const float4 e0 = pick(et, t0), ee1 = pick(et, t1), ee2 = pick(et, t2), ee3 = pick(et, t3);
-        acc.x += fmaxf(x0.x + e0.x, 0.f); acc.y += fmaxf(x0.y + e0.y, 0.f);
-        acc.z += fmaxf(x0.z + e0.z, 0.f); acc.w += fmaxf(x0.w + e0.w, 0.f);
-        if (m > 1) { acc.x += fmaxf(x1.x + ee1.x, 0.f); acc.y += fmaxf(x1.y + ee1.y, 0.f);
-                     acc.z += fmaxf(x1.z + ee1.z, 0.f); acc.w += fmaxf(x1.w + ee1.w, 0.f); }
-        if (m > 2) { acc.x += fmaxf(x2.x + ee2.x, 0.f); acc.y += fmaxf(x2.y + ee2.y, 0.f);
-                     acc.z += fmaxf(x2.z + ee2.z, 0.f); acc.w += fmaxf(x2.w + ee2.w, 0.f); }
-        if (m > 3) { acc.x += fmaxf(x3.x + ee3.x, 0.f); acc.y += fmaxf(x3.y + ee3.y, 0.f);
-                     acc.z += fmaxf(x3.z + ee3.z, 0.f); acc.w += fmaxf(x3.w + ee3.w, 0.f); }
+    const int H = a.H4 * 4;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
+    stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
+    // a block walks the (node, channel chunk) items with the grid's stride, so the table is staged once per block
+    const long long total = (long long)a.n * a.H4;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / a.H4), c = (int)(t - (long long)i * a.H4) * 4;
+        const float4 xi = ld4(g.x + (long long)i * a.ldx + c);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int e1 = g.rowptr[i + 1];
+        // neighbours in groups of 4: all index loads, then all row loads, are issued together (one latency
+        // round trip per group instead of per edge); the sum keeps edge order.  Every load is unconditional
+        // (a load under a branch makes the compiler wait for everything in flight at each join): slots past
+        // the row's end re-read its last edge with bond type 4, whose table row is -inf, so that their
+        // message relu(x + -inf) is exactly 0.
+        for (int e = g.rowptr[i]; e < e1; e += 4) {
+            const int last = e1 - 1;
+            const int eb = min(e + 1, last), ec = min(e + 2, last), ed = min(e + 3, last);
+            const int j0 = g.col[e], j1 = g.col[eb], j2 = g.col[ec], j3 = g.col[ed];
+            const int t0 = g.etype[e] & 3, t1 = e + 1 > last ? 4 : g.etype[eb] & 3;
+            const int t2 = e + 2 > last ? 4 : g.etype[ec] & 3, t3 = e + 3 > last ? 4 : g.etype[ed] & 3;
+            const float4 x0 = ld4(g.x + (long long)j0 * a.ldx + c), x1 = ld4(g.x + (long long)j1 * a.ldx + c);
+            const float4 x2 = ld4(g.x + (long long)j2 * a.ldx + c), x3 = ld4(g.x + (long long)j3 * a.ldx + c);
+            const float4 e0 = *reinterpret_cast<const float4*>(etab_lds + t0 * H + c);
+            const float4 ee1 = *reinterpret_cast<const float4*>(etab_lds + t1 * H + c);
+            const float4 ee2 = *reinterpret_cast<const float4*>(etab_lds + t2 * H + c);
+            const float4 ee3 = *reinterpret_cast<const float4*>(etab_lds + t3 * H + c);
+            acc.x += fmaxf(x0.x + e0.x, 0.f); acc.y += fmaxf(x0.y + e0.y, 0.f);
+            acc.z += fmaxf(x0.z + e0.z, 0.f); acc.w += fmaxf(x0.w + e0.w, 0.f);
+            acc.x += fmaxf(x1.x + ee1.x, 0.f); acc.y += fmaxf(x1.y + ee1.y, 0.f);
+            acc.z += fmaxf(x1.z + ee1.z, 0.f); acc.w += fmaxf(x1.w + ee1.w, 0.f);
+            acc.x += fmaxf(x2.x + ee2.x, 0.f); acc.y += fmaxf(x2.y + ee2.y, 0.f);
+            acc.z += fmaxf(x2.z + ee2.z, 0.f); acc.w += fmaxf(x2.w + ee2.w, 0.f);
+            acc.x += fmaxf(x3.x + ee3.x, 0.f); acc.y += fmaxf(x3.y + ee3.y, 0.f);
+            acc.z += fmaxf(x3.z + ee3.z, 0.f); acc.w += fmaxf(x3.w + ee3.w, 0.f);
+        }
+        st4(g.out + (long long)i * a.ldo + c,
+            make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
     }
-    st4(g.out + (long long)i * a.ldo + c,
-        make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
 }
 
 struct AggBwdArgs { AggBwdGroup g[2]; int ldda, ldx, lddx, ldp, n, H4, H4b, nps; const int32_t* node_graph; };
@@ -76,13 +87,17 @@ struct AggBwdArgs { AggBwdGroup g[2]; int ldda, ldx, lddx, ldp, n, H4, H4b, nps;
 // combines its slots in order through LDS and writes one [4][H] partial per node block.
 __global__ __launch_bounds__(256) void gine_agg_bwd_kernel(const AggBwdArgs a) {
     __shared__ float4 part[4][256];
+    extern __shared__ __attribute__((aligned(16))) float etab_lds[];
     const AggBwdGroup& g = a.g[blockIdx.y];
     const int tid = threadIdx.x;
     const int slot = tid / a.H4b, cl = tid - slot * a.H4b, c4 = blockIdx.z * a.H4b + cl, c = c4 * 4;
     const bool lane_on = slot < a.nps && c4 < a.H4;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-    EdgeTab et;
-    if (lane_on && g.da) et = load_edge_tab(g.edge_w, g.edge_b, c);
+    const int H = a.H4 * 4;
+    if (g.da) {   // uniform over the block
+        for (int k = tid; k < H; k += 256) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
+        stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
+    }
     const int node0 = blockIdx.x * a.nps * AGG_BWD_PASSES;
     for (int pass = 0; pass < AGG_BWD_PASSES; ++pass) {
         const int j = node0 + pass * a.nps + slot;
@@ -91,26 +106,29 @@ __global__ __launch_bounds__(256) void gine_agg_bwd_kernel(const AggBwdArgs a) {
         if (g.da) {
             const float4 xj = ld4(g.x + (long long)j * a.ldx + c);
             const int e1 = g.rowptr_t[j + 1];
-            for (int e = g.rowptr_t[j]; e < e1; e += 4) {   // groups of 4, as in the forward kernel
-                const int m = e1 - e;
-                const int i0 = g.col_t[e], i1 = m > 1 ? g.col_t[e + 1] : i0, i2 = m > 2 ? g.col_t[e + 2] : i0, i3 = m > 3 ? g.col_t[e + 3] : i0;
-                const int t0 = g.etype_t[e], t1 = m > 1 ? g.etype_t[e + 1] : 0, t2 = m > 2 ? g.etype_t[e + 2] : 0, t3 = m > 3 ? g.etype_t[e + 3] : 0;
+            for (int e = g.rowptr_t[j]; e < e1; e += 4) {   // groups of 4 with unconditional loads, as in the forward kernel
+                const int last = e1 - 1;
+                const int eb = min(e + 1, last), ec = min(e + 2, last), ed = min(e + 3, last);
+                const int i0 = g.col_t[e], i1 = g.col_t[eb], i2 = g.col_t[ec], i3 = g.col_t[ed];
+                const int t0 = g.etype_t[e] & 3, t1 = e + 1 > last ? 4 : g.etype_t[eb] & 3;
+                const int t2 = e + 2 > last ? 4 : g.etype_t[ec] & 3, t3 = e + 3 > last ? 4 : g.etype_t[ed] & 3;
                 const float4 d0 = ld4(g.da + (long long)i0 * a.ldda + c), d1 = ld4(g.da + (long long)i1 * a.ldda + c);
                 const float4 d2 = ld4(g.da + (long long)i2 * a.ldda + c), d3 = ld4(g.da + (long long)i3 * a.ldda + c);
                 const float4 dd[4] = {d0, d1, d2, d3};
                 const int tt[4] = {t0, t1, t2, t3};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (q < m) {
-                        const float4 ee = pick(et, tt[q]);
-                        const float4 v = make_float4(xj.x + ee.x > 0.f ? dd[q].x : 0.f, xj.y + ee.y > 0.f ? dd[q].y : 0.f,
-                                                     xj.z + ee.z > 0.f ? dd[q].z : 0.f, xj.w + ee.w > 0.f ? dd[q].w : 0.f);
-                        acc = add4(acc, v);
-                        if (tt[q] == 1) s1 = add4(s1, v);
-                        else if (tt[q] == 2) s2 = add4(s2, v);
-                        else if (tt[q] == 3) s3 = add4(s3, v);
-                        else s0 = add4(s0, v);
-                    }
+                    // an empty slot has type 4, whose table row is -inf: its gate is closed and v = 0
+                    const float4 ee = *reinterpret_cast<const float4*>(etab_lds + tt[q] * H + c);
+                    const float4 v = make_float4(xj.x + ee.x > 0.f ? dd[q].x : 0.f, xj.y + ee.y > 0.f ? dd[q].y : 0.f,
+                                                 xj.z + ee.z > 0.f ? dd[q].z : 0.f, xj.w + ee.w > 0.f ? dd[q].w : 0.f);
+                    acc = add4(acc, v);
+                    // per-type sums: s_k += [type == k] * v, one fused multiply-add each (exactly s_k + v or s_k)
+                    const float m0 = tt[q] == 0 ? 1.f : 0.f, m1 = tt[q] == 1 ? 1.f : 0.f, m2 = tt[q] == 2 ? 1.f : 0.f, m3 = tt[q] == 3 ? 1.f : 0.f;
+                    s0 = make_float4(fmaf(m0, v.x, s0.x), fmaf(m0, v.y, s0.y), fmaf(m0, v.z, s0.z), fmaf(m0, v.w, s0.w));
+                    s1 = make_float4(fmaf(m1, v.x, s1.x), fmaf(m1, v.y, s1.y), fmaf(m1, v.z, s1.z), fmaf(m1, v.w, s1.w));
+                    s2 = make_float4(fmaf(m2, v.x, s2.x), fmaf(m2, v.y, s2.y), fmaf(m2, v.z, s2.z), fmaf(m2, v.w, s2.w));
+                    s3 = make_float4(fmaf(m3, v.x, s3.x), fmaf(m3, v.y, s3.y), fmaf(m3, v.z, s3.z), fmaf(m3, v.w, s3.w));
                 }
             }
             const float4 dj = ld4(g.da + (long long)j * a.ldda + c);
@@ -354,6 +372,7 @@ inline int grid_for(long long items, int block, int cap = 4096) {
 int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo, int n, int H) {
     if (n == 0) return 0;
     if (H % 4 || ldx % 4 || ldo % 4) return PSVAE_E_ALIGN;
+    if (H > 3072) return PSVAE_E_SHAPE;   // the edge table of a block lives in LDS (20 bytes per channel)
     if (ngroups < 1 || ngroups > 2) return PSVAE_E_SHAPE;
     AggArgs a;
     for (int k = 0; k < ngroups; ++k) {
@@ -363,11 +382,13 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     if (ngroups == 1) a.g[1] = g[0];
     a.ldx = ldx; a.ldo = ldo; a.n = n; a.H4 = H / 4;
     const long long items = (long long)n * a.H4;
-    dim3 grid((unsigned)((items + 255) / 256), ngroups);
+    const long long blocks = (items + 255) / 256;
+    static const long long cap = [] { const char* e = getenv("PSVAE_AGG_BLOCKS"); return e ? atoll(e) : (long long)AGG_FWD_MAX_BLOCKS; }();
+    dim3 grid((unsigned)(blocks < cap ? blocks : cap), ngroups);
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += 2.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1);
     ProfScope prof(s, KC_AGG_FWD, bytes);
-    hipLaunchKernelGGL(gine_agg_fwd_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gine_agg_fwd_kernel, grid, dim3(256), (size_t)20 * H, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -383,6 +404,9 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     if (n == 0) return 0;
     if (H % 4 || ldda % 4 || ldx % 4 || lddx % 4 || ldp % 4) return PSVAE_E_ALIGN;
     if (ngroups < 1 || ngroups > 2 || H < 4) return PSVAE_E_SHAPE;
+    bool need_tab = false;
+    for (int k = 0; k < ngroups; ++k) need_tab = need_tab || g[k].da != nullptr;
+    if (need_tab && H > 2048) return PSVAE_E_SHAPE;   // the edge table sits in LDS (20 bytes per channel) beside the partials
     AggBwdArgs a;
     for (int k = 0; k < ngroups; ++k) {
         a.g[k] = g[k];
@@ -398,7 +422,7 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += g[k].da ? 3.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1) : 2.0 * n * 4 * H;
     ProfScope prof(s, KC_AGG_BWD, bytes);
-    hipLaunchKernelGGL(gine_agg_bwd_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gine_agg_bwd_kernel, grid, dim3(256), need_tab ? (size_t)20 * H : 0, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
