@@ -326,34 +326,71 @@ __global__ __launch_bounds__(256) void pair_gather_kernel(const float* __restric
     }
 }
 
-// demb[j] = sum_{s: src_s = j} dpin[s, 0:H] + sum_{s: dst_s = j} dpin[s, H:2H]   (rows 0..n-1)
-// dz[b]  (+)= sum_{s in graph b} dpin[s, 2H:2H+Z]                                (rows n..n+B-1 of the grid)
+// demb[j] = sum_{s: src_s = j} dpin[s, 0:H] + sum_{s: dst_s = j} dpin[s, H:2H]   (blocks 0..node_blocks-1)
+// dz[b]  (+)= sum_{s in graph b} dpin[s, 2H:2H+Z]                                (one block per graph after them)
+// Index and row loads go out four at a time (slots past the end re-read the last entry and add 0), so a
+// node costs two memory round trips per four pairs instead of two per pair.  A graph's latent gradient is
+// summed by 16 slots that stride over its pairs and are then combined in slot order through LDS.
+__device__ __forceinline__ float4 sum_rows4(const float* __restrict__ base, int P, int off, const int32_t* __restrict__ idx,
+                                            int k0, int k1, float4 acc) {
+    for (int k = k0; k < k1; k += 4) {
+        const int last = k1 - 1;
+        const int r0 = idx[k], r1 = idx[min(k + 1, last)], r2 = idx[min(k + 2, last)], r3 = idx[min(k + 3, last)];
+        const float4 v0 = ld4(base + (long long)r0 * P + off), v1 = ld4(base + (long long)r1 * P + off);
+        const float4 v2 = ld4(base + (long long)r2 * P + off), v3 = ld4(base + (long long)r3 * P + off);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = add4(acc, v0);
+        acc = add4(acc, k + 1 <= last ? v1 : zero);
+        acc = add4(acc, k + 2 <= last ? v2 : zero);
+        acc = add4(acc, k + 3 <= last ? v3 : zero);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void pair_scatter_kernel(const float* __restrict__ dpin, int P,
                                                            const int32_t* __restrict__ sp, const int32_t* __restrict__ si,
                                                            const int32_t* __restrict__ dp, const int32_t* __restrict__ di,
                                                            const int32_t* __restrict__ goff, float* __restrict__ demb,
                                                            int ldde, float* __restrict__ dz, int dz_acc, int n, int B,
-                                                           int H4, int Z4) {
-    const long long nodes_items = (long long)n * H4;
-    const long long total = nodes_items + (long long)B * Z4;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    if (t < nodes_items) {
+                                                           int H4, int Z4, int node_blocks) {
+    __shared__ float4 part[16][16];
+    if ((int)blockIdx.x < node_blocks) {
+        const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= (long long)n * H4) return;
         const int j = (int)(t / H4), c = (int)(t - (long long)j * H4) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = sp[j]; k < sp[j + 1]; ++k) acc = add4(acc, ld4(dpin + (long long)si[k] * P + c));
-        const int H = H4 * 4;
-        for (int k = dp[j]; k < dp[j + 1]; ++k) acc = add4(acc, ld4(dpin + (long long)di[k] * P + H + c));
+        acc = sum_rows4(dpin, P, c, si, sp[j], sp[j + 1], acc);
+        acc = sum_rows4(dpin, P, H4 * 4 + c, di, dp[j], dp[j + 1], acc);
         st4(demb + (long long)j * ldde + c, acc);
-    } else {
-        const long long u = t - nodes_items;
-        const int b = (int)(u / Z4), c = (int)(u - (long long)b * Z4) * 4;
+        return;
+    }
+    const int b = blockIdx.x - node_blocks, slot = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int s0 = goff[b], s1 = goff[b + 1], off = 2 * H4 * 4;
+    for (int c4 = cq; c4 - cq < Z4; c4 += 16) {      // uniform trip count over the block
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int off = 2 * H4 * 4;
-        for (int s = goff[b]; s < goff[b + 1]; ++s) acc = add4(acc, ld4(dpin + (long long)s * P + off + c));
-        float* d = dz + (long long)b * (Z4 * 4) + c;
-        if (dz_acc) acc = add4(acc, ld4(d));
-        st4(d, acc);
+        if (c4 < Z4) {
+            const float* col = dpin + off + c4 * 4;
+            for (int s = s0 + slot; s < s1; s += 64) {
+                const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int last = s1 - 1;
+                const float4 v0 = ld4(col + (long long)s * P), v1 = ld4(col + (long long)min(s + 16, last) * P);
+                const float4 v2 = ld4(col + (long long)min(s + 32, last) * P), v3 = ld4(col + (long long)min(s + 48, last) * P);
+                acc = add4(acc, v0);
+                acc = add4(acc, s + 16 <= last ? v1 : zero);
+                acc = add4(acc, s + 32 <= last ? v2 : zero);
+                acc = add4(acc, s + 48 <= last ? v3 : zero);
+            }
+        }
+        part[slot][cq] = acc;
+        __syncthreads();
+        if (slot == 0 && c4 < Z4) {
+            float4 v = part[0][cq];
+            for (int q = 1; q < 16; ++q) v = add4(v, part[q][cq]);
+            float* d = dz + (long long)b * (Z4 * 4) + c4 * 4;
+            if (dz_acc) v = add4(v, ld4(d));
+            st4(d, v);
+        }
+        __syncthreads();
     }
 }
 
@@ -526,8 +563,10 @@ int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_
     const long long items = (long long)n * (H / 4) + (long long)B * (Z / 4);
     if (items == 0) return 0;
     ProfScope prof(s, KC_PAIR_SCATTER, (double)items * 16.0 * 2);
-    hipLaunchKernelGGL(pair_scatter_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, dpin, P, by_src_ptr,
-                       by_src_idx, by_dst_ptr, by_dst_idx, pair_graph_off, demb, ldde, dz, dz_accumulate, n, B, H / 4, Z / 4);
+    const int node_blocks = (int)(((long long)n * (H / 4) + 255) / 256);
+    hipLaunchKernelGGL(pair_scatter_kernel, dim3((unsigned)(node_blocks + B)), dim3(256), 0, s, dpin, P, by_src_ptr,
+                       by_src_idx, by_dst_ptr, by_dst_idx, pair_graph_off, demb, ldde, dz, dz_accumulate, n, B, H / 4, Z / 4,
+                       node_blocks);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -127,30 +127,30 @@ __global__ void mse_bwd_kernel(const float* __restrict__ pred, int ldp, const fl
     dpred[(long long)b * ldp + k] = 2.0f * (pred[(long long)b * ldp + k] - gold[t]) * gscale[0] / denoms[3];
 }
 
-// Block-wide sum in a fixed order: thread-strided partials, then an LDS tree.
-__device__ float block_sum_256(const float* __restrict__ v, int n, float* sh) {
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    const float r = sh[0];
-    __syncthreads();
-    return r;
-}
 // losses = [pred, rec, piece, edge, kl]
 __global__ __launch_bounds__(256) void losses_finalize_kernel(const float* mse_row, int B, const float* piece_row, int rows_p,
                                                               const float* edge_row, int S, const float* klrow,
                                                               const float* denoms, float w_pred, float w_rec, float w_kl,
                                                               float* losses) {
-    __shared__ float sh[256];
-    const float mse = block_sum_256(mse_row, B, sh);
-    const float piece = block_sum_256(piece_row, rows_p, sh);
-    const float edge = block_sum_256(edge_row, S, sh);
-    const float kl = block_sum_256(klrow, B, sh);
+    // four block-wide sums in a fixed order (thread-strided partials, then an LDS tree), with the loads of
+    // all four in flight together and one tree for the four of them: this kernel sits between forward and
+    // backward on the caller's stream, so its latency is paid in full on every step
+    __shared__ float sh[4][256];
+    const int tid = threadIdx.x;
+    const int nmax = max(max(B, rows_p), S);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = tid; i < nmax; i += 256) {
+        const float a0 = mse_row[max(0, min(i, B - 1))], a1 = piece_row[max(0, min(i, rows_p - 1))];
+        const float a2 = edge_row[max(0, min(i, S - 1))], a3 = klrow[max(0, min(i, B - 1))];
+        s0 += i < B ? a0 : 0.f; s1 += i < rows_p ? a1 : 0.f; s2 += i < S ? a2 : 0.f; s3 += i < B ? a3 : 0.f;
+    }
+    sh[0][tid] = s0; sh[1][tid] = s1; sh[2][tid] = s2; sh[3][tid] = s3;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; sh[2][tid] += sh[2][tid + o]; sh[3][tid] += sh[3][tid + o]; }
+        __syncthreads();
+    }
+    const float mse = sh[0][0], piece = sh[1][0], edge = sh[2][0], kl = sh[3][0];
     if (threadIdx.x == 0) {
         const float pl = piece / denoms[0], el = edge / denoms[1];
         losses[0] = mse / denoms[3];
