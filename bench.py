@@ -127,9 +127,14 @@ def main():
     # Rehearsal only (gloo, fewer GPUs than ranks): processes that share a GPU must not block on a collective
     # while their own queue still holds work that waits for it, or the other process may never get the GPU.
     shared_gpu = world > max(n_dev, 1)
-    if world > 1:
+    # PSVAE_BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL path on one GPU)
+    dist_on = world > 1 or os.environ.get('PSVAE_BENCH_FORCE_DIST') == '1'
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group(backend='nccl', device_id=dev)
         else:
@@ -143,7 +148,7 @@ def main():
     cpu_batches, collate_s = make_batches(tok, args.vocab, args.shape, args.batch_size, n_distinct, seed=2021 + rank)
     batches = [to_device(b, dev) for b in cpu_batches]
     model.flat_buffers()
-    reducer = GradReducer([0, model._n_trained])     # one collective for the whole gradient (7.6 MB)
+    reducer = GradReducer([0, model._n_trained], always=dist_on)     # one collective for the whole gradient (7.6 MB)
     local_denoms = [b['_native'].denoms.clone() for b in batches]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
@@ -158,7 +163,7 @@ def main():
 
     def step(i):
         batch = batches[i % n_distinct]
-        if world > 1:
+        if dist_on:
             if i not in pending:
                 exchange_denoms(i)
             work = pending.pop(i)
@@ -168,7 +173,7 @@ def main():
         opt.zero_grad()
         loss = model.training_step(batch, eps=eps)
         loss.backward()
-        if world > 1:
+        if dist_on:
             if shared_gpu:
                 torch.cuda.synchronize()
             reducer.reduce_grads(model.flat_buffers()[1])
@@ -180,7 +185,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +201,7 @@ def main():
     host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
@@ -220,7 +225,7 @@ def main():
     ev_ms = max(0.0, float(L.psvae_profile_event_overhead_ms(torch.cuda.current_stream().cuda_stream)))
     classes = {k: (max(ms - cnt * ev_ms, 0.05 * ms), work, cnt) for k, (ms, work, cnt) in raw.items()}
 
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:

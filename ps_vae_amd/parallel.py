@@ -34,10 +34,12 @@ class GradReducer:
     choice; `model.bucket_bounds` lists where backward finishes groups of
     parameters, for callers that overlap."""
 
-    def __init__(self, bounds, group=None):
+    def __init__(self, bounds, group=None, always=False):
         self.bounds = list(bounds)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # `always`: issue the collectives even in a group of one (rehearses the RCCL path on a single GPU)
+        self.active = dist.is_initialized() and (self.world > 1 or always)
         # gloo moves GPU tensors through host memory anyway; doing that copy here keeps gloo on its CPU path
         self.stage_on_host = dist.is_initialized() and dist.get_backend(group) == 'gloo'
 
@@ -54,11 +56,11 @@ class GradReducer:
         enqueued (it depends on nothing but the batch, so it can run a step ahead); the returned handle's
         `wait()` makes the current stream wait for it.  Returns `out`, or `(out, handle)`."""
         out = local_denoms.clone() if out is None else out.copy_(local_denoms)
-        work = self._all_reduce(out, async_op=async_op) if self.world > 1 else None
+        work = self._all_reduce(out, async_op=async_op) if self.active else None
         return (out, work) if async_op else out
 
     def reduce_grads(self, flat_grads, async_op=False):
-        if self.world == 1:
+        if not self.active:
             return []
         works = []
         for lo, hi in zip(self.bounds[:-1], self.bounds[1:]):

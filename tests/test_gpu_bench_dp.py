@@ -26,3 +26,17 @@ def test_bench_two_ranks_over_gloo():
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['global_batch'] == 256
     assert res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']   # finite, not NaN
     assert res['roofline']['frac'] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_collectives_over_rccl_with_one_rank():
+    """The RCCL code path (process group on the device, all-reduce of the flat gradient, look-ahead
+    all-reduce of the denominators) with the one rank a single-GPU box allows."""
+    env = dict(os.environ, PSVAE_BENCH_FORCE_DIST='1', PSVAE_BENCH_WATCHDOG='200', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT='29537', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
+           '--profile-steps', '1']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert res['n_gpus'] == 1 and res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']
