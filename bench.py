@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config, synth  # noqa: E402
 from ps_vae_amd import _lib  # noqa: E402
-from ps_vae_amd.data import BPEMolDataset, to_device  # noqa: E402
+from ps_vae_amd.data import BPEMolDataset, PackedMolDataset, to_device  # noqa: E402
 from ps_vae_amd.parallel import GradReducer  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
@@ -33,15 +33,30 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f
 FLOP_CLASSES = ('gemm_forward', 'gemm_input_grad', 'gemm_weight_grad', 'gru_forward', 'gru_backward')
 
 
-def make_batches(tok, vocab, shape, batch_size, count, seed):
+def make_batches(tok, vocab, shape, batch_size, count, seed, host_times=None):
+    """`count` collated batches and the seconds stage 3 took per batch.  `host_times` (dict) also receives
+    what one DataLoader worker pays per batch on the two host paths: stage 2 + 3 per item
+    (`BPEMolDataset`) and the flattened data set with both stages native (`PackedMolDataset`)."""
     random.seed(seed)
-    out, t_collate = [], 0.0
+    out, t_collate, t_item, t_packed = [], 0.0, 0.0, 0.0
     for i in range(count):
         mols = synth.make_molecules(seed * 1000 + i, shape, vocab, batch_size)
-        step2 = [BPEMolDataset.process_step2(m, tok) for m in mols]
         t0 = time.perf_counter()
+        step2 = [BPEMolDataset.process_step2(m, tok, lists=False) for m in mols]
+        t1 = time.perf_counter()
         out.append(BPEMolDataset.process_step3(step2, tok))
-        t_collate += time.perf_counter() - t0
+        t2 = time.perf_counter()
+        t_collate += t2 - t1
+        t_item += t2 - t0
+        if host_times is not None:
+            state = random.getstate()
+            ds = PackedMolDataset(mols, tok)
+            t3 = time.perf_counter()
+            ds.collate_fn(list(range(batch_size)))
+            t_packed += time.perf_counter() - t3
+            random.setstate(state)
+    if host_times is not None:
+        host_times.update(per_item_ms=t_item / count * 1e3, packed_ms=t_packed / count * 1e3)
     return out, t_collate / count
 
 
@@ -145,7 +160,9 @@ def main():
     model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)
     opt = model.configure_optimizers()
     n_distinct = 8
-    cpu_batches, collate_s = make_batches(tok, args.vocab, args.shape, args.batch_size, n_distinct, seed=2021 + rank)
+    host_times = {}
+    cpu_batches, collate_s = make_batches(tok, args.vocab, args.shape, args.batch_size, n_distinct, seed=2021 + rank,
+                                          host_times=host_times)
     batches = [to_device(b, dev) for b in cpu_batches]
     model.flat_buffers()
     reducer = GradReducer([0, model._n_trained], always=dist_on)     # one collective for the whole gradient (7.6 MB)
@@ -266,6 +283,8 @@ def main():
                                f'(fwd + bwd + clip + Adam{f" + grad all-reduce over {comm}" if world > 1 else ""})',
                    'global_batch': world * args.batch_size, 'parallelism': f'dp{world}', 'params': int(model._n_trained),
                    'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3,
+                   'host_stage2_plus_3_ms_per_batch': host_times.get('per_item_ms'),
+                   'host_packed_dataset_ms_per_batch': host_times.get('packed_ms'),
                    'host_enqueue_ms_per_step': host_enqueue_s / args.steps * 1e3},
         'roofline': roofline,
         'message_passing': {'kernels': mp, 'bound': 'hbm', 'achieved': (mp_bytes / (mp_ms * 1e-3) / 1e9) if mp_ms else None,

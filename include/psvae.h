@@ -278,6 +278,19 @@ int psvae_collate_pairs(int B, int N, const int32_t* n_atoms, const int8_t* ad, 
                         int32_t* in_piece_idx, int64_t* n_in_piece,
                         int32_t* pair_graph, int32_t* pair_m, int32_t* pair_n, int32_t* pair_gold,
                         int64_t pair_cap, int64_t* n_pairs);
+/* Stage 2 of the dataset (process_step2, src/data/bpe_dataset.py:56-84) for B molecules `idx` of a data set
+ * flattened beforehand: atoms of molecule m are atom_off[m]..atom_off[m+1] of x_all / piece_of_atom /
+ * pos_of_atom / group_of_atom (group = index into the record's `groups`, -1 for none), its bonds
+ * bond_off[m]..bond_off[m+1] of bond_a/bond_b/bond_t (local atom numbers, list order: a later duplicate
+ * overwrites), its piece sequence piece_off[m]..piece_off[m+1] of pieces_all.  Writes what stage 3 consumes:
+ * n_atoms [B], the padded x / x_pieces / x_pos [B,N] and pieces [B,L], and the concatenated dense
+ * bond-type and cross-piece matrices (sum of n_i*n_i bytes each; matrix_bytes = their capacity). */
+int psvae_gather_molecules(int B, const int64_t* idx, const int64_t* atom_off, const int32_t* x_all,
+                           const int32_t* piece_of_atom, const int32_t* pos_of_atom, const int32_t* group_of_atom,
+                           const int64_t* bond_off, const int32_t* bond_a, const int32_t* bond_b, const int8_t* bond_t,
+                           const int64_t* piece_off, const int32_t* pieces_all, int N, int L, int atom_pad,
+                           int piece_pad, int32_t* n_atoms, int32_t* x, int32_t* x_pieces, int32_t* x_pos,
+                           int32_t* pieces, int8_t* ad, int8_t* cross, int64_t matrix_bytes);
 /* Build the packed index blob of psvae_batch from padded-numbering arrays.
  * `blob` receives int32 words; `offsets[PSVAE_BLOB_FIELDS]` the start of each
  * field inside it (field order = PSVAE_BLOB_* below).  Returns words used via

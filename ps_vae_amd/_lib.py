@@ -128,6 +128,7 @@ def lib():
     L.psvae_softmax_ce_forward.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.psvae_collate_pairs.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp, i64, P(i64), vp, P(i64),
                                       vp, vp, vp, vp, i64, P(i64)]
+    L.psvae_gather_molecules.argtypes = [C.c_int] + [vp] * 12 + [C.c_int] * 4 + [vp] * 7 + [i64]
     L.psvae_pack_bound.restype = i64
     L.psvae_pack_bound.argtypes = [C.c_int, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.psvae_pack_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp,
@@ -152,7 +153,7 @@ EXPORTS = (
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',
-    'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs',
+    'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs', 'psvae_gather_molecules',
     'psvae_pack_bound', 'psvae_pack_batch', 'psvae_profile_enable', 'psvae_profile_num_classes',
     'psvae_profile_class_name', 'psvae_profile_collect', 'psvae_profile_event_overhead_ms')
 

@@ -91,6 +91,52 @@ extern "C" int psvae_collate_pairs(int B, int N, const int32_t* n_atoms, const i
     return 0;
 }
 
+// Stage 2 of the dataset (src/data/bpe_dataset.py:56-84) for the molecules `idx[0..B)` of a flattened
+// data set, straight into the padded arrays and the concatenated matrices stage 3 walks.
+extern "C" int psvae_gather_molecules(int B, const int64_t* idx, const int64_t* atom_off, const int32_t* x_all,
+                                      const int32_t* piece_of_atom, const int32_t* pos_of_atom, const int32_t* group_of_atom,
+                                      const int64_t* bond_off,
+                                      const int32_t* bond_a, const int32_t* bond_b, const int8_t* bond_t,
+                                      const int64_t* piece_off, const int32_t* pieces_all, int N, int L, int atom_pad,
+                                      int piece_pad, int32_t* n_atoms, int32_t* x, int32_t* x_pieces, int32_t* x_pos,
+                                      int32_t* pieces, int8_t* ad, int8_t* cross, int64_t matrix_bytes) {
+    if (!idx || !atom_off || !x_all || !piece_of_atom || !pos_of_atom || !group_of_atom || !bond_off || !piece_off || !pieces_all ||
+        !n_atoms || !x || !x_pieces || !x_pos || !pieces || !ad || !cross) return PSVAE_E_NULL;
+    if (B < 1 || N < 1 || L < 1) return PSVAE_E_SHAPE;
+    int64_t base = 0;
+    for (int i = 0; i < B; ++i) {
+        const int64_t m = idx[i], a0 = atom_off[m];
+        const int64_t n = atom_off[m + 1] - a0, np = piece_off[m + 1] - piece_off[m];
+        if (n < 0 || n > N || np < 0 || np > L) return PSVAE_E_SHAPE;
+        if (base + n * n > matrix_bytes) return PSVAE_E_CAPACITY;
+        n_atoms[i] = (int32_t)n;
+        for (int64_t k = 0; k < N; ++k) {
+            const bool real = k < n;
+            x[(int64_t)i * N + k] = real ? x_all[a0 + k] : atom_pad;
+            x_pieces[(int64_t)i * N + k] = real ? piece_of_atom[a0 + k] : piece_pad;
+            x_pos[(int64_t)i * N + k] = real ? pos_of_atom[a0 + k] : 0;
+        }
+        for (int64_t k = 0; k < L; ++k) pieces[(int64_t)i * L + k] = k < np ? pieces_all[piece_off[m] + k] : piece_pad;
+        int8_t* A = ad + base;
+        int8_t* C = cross + base;
+        memset(A, 0, (size_t)(n * n));
+        for (int64_t e = bond_off[m]; e < bond_off[m + 1]; ++e) {      // list order: a later duplicate overwrites (:62-66)
+            const int32_t u = bond_a[e], v = bond_b[e];
+            if (u < 0 || v < 0 || u >= n || v >= n) return PSVAE_E_SHAPE;
+            A[(int64_t)u * n + v] = bond_t[e];
+            A[(int64_t)v * n + u] = bond_t[e];
+        }
+        // cross-piece mask (:68-82): 1 unless both atoms lie in the same group; an atom of no group (-1)
+        // keeps its row of ones
+        for (int64_t u = 0; u < n; ++u) {
+            const int32_t gu = group_of_atom[a0 + u];
+            for (int64_t v = 0; v < n; ++v) C[u * n + v] = (gu < 0 || gu != group_of_atom[a0 + v]) ? 1 : 0;
+        }
+        base += n * n;
+    }
+    return 0;
+}
+
 extern "C" int64_t psvae_pack_bound(int B, int N, int64_t n_edges, int64_t n_pairs, int L, int num_atom, int num_piece,
                                     int max_pos) {
     const int64_t n = (int64_t)B * N;

@@ -116,30 +116,42 @@ class BPEMolDataset(torch.utils.data.Dataset):
                            '(reference: src/data/bpe_dataset.py:31-54)')
 
     @staticmethod
-    def process_step2(data, tokenizer):
+    def process_step2(data, tokenizer, lists=True):
         """Adjacency-matrix form (`bpe_dataset.py:56-84`).  Besides the reference's
         keys the result carries the two matrices as int8 arrays (`_ad`, `_cross`)
-        so that stage 3 need not re-walk nested lists."""
+        so that stage 3 need not re-walk nested lists.  `lists=False` (what the
+        dataset's `__getitem__` uses) leaves `ad_mat`, `edge_select`, `x_pieces`
+        and `x_pos` as numpy arrays instead of converting them to nested Python
+        lists, which is most of this stage's cost; they index the same way."""
         n = len(data['x'])
         ad = np.zeros((n, n), dtype=np.int8)
         if len(data['edge_attr']):
             ei = np.asarray(data['edge_index'], dtype=np.int64).reshape(-1, 2)
             et = np.asarray(data['edge_attr'], dtype=np.int8)
-            for (a, b), t in zip(ei, et):      # later duplicates overwrite, as in the reference
-                ad[a, b] = ad[b, a] = t
-        cross = np.ones((n, n), dtype=np.int8)
+            # both directions of every bond in list order: later duplicates overwrite, as in the reference
+            rows = np.stack([ei[:, 0], ei[:, 1]], axis=1).ravel()
+            cols = np.stack([ei[:, 1], ei[:, 0]], axis=1).ravel()
+            ad[rows, cols] = np.repeat(et, 2)
+        pieces = data['pieces']
+        gid = np.full(n, -1, dtype=np.int64)
         x_pieces = np.zeros(n, dtype=np.int64)
         x_pos = np.zeros(n, dtype=np.int64)
-        pieces = data['pieces']
-        for pos, group in enumerate(data['groups']):
-            if len(group):
-                g = np.asarray(group, dtype=np.int64)
-                cross[np.ix_(g, g)] = 0
-                x_pieces[g] = pieces[pos]
-                x_pos[g] = pos
-        return {'x': list(data['x']), 'ad_mat': ad.tolist(), 'props': data['props'], 'pieces': pieces,
-                'x_pieces': x_pieces.tolist(), 'x_pos': x_pos.tolist(), 'edge_select': cross.tolist(),
-                '_ad': ad, '_cross': cross}
+        groups = data['groups']
+        glen = np.fromiter((len(g) for g in groups), dtype=np.int64, count=len(groups))
+        if glen.sum():
+            flat = np.fromiter((a for g in groups for a in g), dtype=np.int64, count=int(glen.sum()))
+            pos_of = np.repeat(np.arange(len(groups), dtype=np.int64), glen)
+            gid[flat] = pos_of                      # in list order: a later group overwrites, as the reference's loop does
+            x_pieces[flat] = np.asarray(pieces, dtype=np.int64)[pos_of]
+            x_pos[flat] = pos_of
+        cross = (gid[:, None] != gid[None, :]) | (gid[:, None] < 0)     # an atom outside every group keeps its row of ones
+        cross = cross.astype(np.int8)
+        out = {'x': list(data['x']), 'props': data['props'], 'pieces': pieces, '_ad': ad, '_cross': cross}
+        if lists:
+            out.update(ad_mat=ad.tolist(), x_pieces=x_pieces.tolist(), x_pos=x_pos.tolist(), edge_select=cross.tolist())
+        else:
+            out.update(ad_mat=ad, x_pieces=x_pieces, x_pos=x_pos, edge_select=cross)
+        return out
 
     @staticmethod
     def process_step3(data_list, tokenizer, device='cpu', all_pairs=False):
@@ -147,7 +159,6 @@ class BPEMolDataset(torch.utils.data.Dataset):
         Python's global `random` stream exactly like the reference: the generator
         state is handed to the native loop and written back afterwards.
         `all_pairs=True` keeps every cross-piece ordered pair (no sampling)."""
-        lib = _lib.lib()
         B = len(data_list)
         lens = np.asarray([len(d['x']) for d in data_list], dtype=np.int32)
         N = int(lens.max())
@@ -163,60 +174,144 @@ class BPEMolDataset(torch.utils.data.Dataset):
             crosses.append(np.ascontiguousarray(d['_cross'] if '_cross' in d else np.asarray(d['edge_select'], dtype=np.int8).reshape(k, k)).ravel())
         ad = np.concatenate(ads) if ads else np.zeros(0, np.int8)
         cross = np.concatenate(crosses) if crosses else np.zeros(0, np.int8)
-        total = int((lens.astype(np.int64) ** 2).sum())
-        e_cap = int(np.count_nonzero(ad)) + 1
-        p_cap = total + 1
-        e_src, e_dst, e_type, in_piece = (np.zeros(e_cap, np.int32) for _ in range(4))
-        pg, pm, pn, pgold = (np.zeros(p_cap, np.int32) for _ in range(4))
-        ne, ni, npair = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        version, state, gauss = random.getstate()
-        mt = np.asarray(state, dtype=np.uint32)
-        rc = lib.psvae_collate_pairs(B, N, _ptr(lens), _ptr(ad), _ptr(cross), 2.0 if all_pairs else NEG_RATE, _ptr(mt),
-                                     _ptr(e_src), _ptr(e_dst), _ptr(e_type), e_cap, C.byref(ne),
-                                     _ptr(in_piece), C.byref(ni), _ptr(pg), _ptr(pm), _ptr(pn), _ptr(pgold), p_cap,
-                                     C.byref(npair))
-        _lib.check(rc, 'psvae_collate_pairs')
-        if not all_pairs:
-            random.setstate((version, tuple(int(v) for v in mt), gauss))
-        ne, ni, npair = ne.value, ni.value, npair.value
-        e_src, e_dst, e_type, in_piece = e_src[:ne], e_dst[:ne], e_type[:ne], in_piece[:ni]
-        pg, pm, pn, pgold = pg[:npair], pm[:npair], pn[:npair], pgold[:npair]
         L = max(len(d['pieces']) for d in data_list)
         pieces = np.full((B, L), pad_piece, dtype=np.int64)
         for i, d in enumerate(data_list):
             pieces[i, :len(d['pieces'])] = d['pieces']
         props = torch.tensor([d['props'] for d in data_list])
-        sel = np.zeros((B, N, N), dtype=bool)
-        sel[pg, pm, pn] = True
-        onehot = np.zeros((ne, 4), dtype=np.int64)
-        onehot[np.arange(ne), e_type] = 1
-        mask = np.arange(N)[None, :] >= lens[:, None]
-        props_sel = props.reshape(B, -1)[:, list(BPEMolDataset.selected_properties)].float().numpy()
-        native = pack_native(lens, N, L, x, xp, xq, e_src, e_dst, e_type, in_piece, pg, pm, pn, pgold, pieces,
-                             props_sel, tokenizer, BPEMolDataset.max_pos)
-        dev = torch.device(device)
-        batch = {
-            'x': torch.from_numpy(x), 'x_pieces': torch.from_numpy(xp), 'x_pos': torch.from_numpy(xq),
-            'atom_mask': torch.from_numpy(mask), 'pieces': torch.from_numpy(pieces),
-            'edge_index': torch.from_numpy(np.stack([e_src, e_dst]).astype(np.int64)) if ne else torch.zeros(2, 0, dtype=torch.long),
-            'edge_attr': torch.from_numpy(onehot), 'edge_select': torch.from_numpy(sel),
-            'golden_edge': torch.from_numpy(pgold.astype(np.int64)),
-            'in_piece_edge_idx': [int(v) for v in in_piece], 'props': props,
-        }
-        if dev.type != 'cpu':
-            batch = to_device(batch, dev)
-            native = native.to(dev)
-        batch['_native'] = native
-        return batch
+        return collate_matrices(lens, N, x, xp, xq, ad, cross, pieces, props, tokenizer, device, all_pairs, True)
 
     def __getitem__(self, idx):
-        return self.process_step2(self.data[idx], self.tokenizer)
+        return self.process_step2(self.data[idx], self.tokenizer, lists=False)
 
     def __len__(self):
         return len(self.data)
 
     def collate_fn(self, data_list):
         return self.process_step3(data_list, self.tokenizer)
+
+
+def collate_matrices(lens, N, x, xp, xq, ad, cross, pieces, props, tokenizer, device='cpu', all_pairs=False, full=True):
+    """The walk of `process_step3` (`bpe_dataset.py:110-132`) over the concatenated bond-type / cross-piece
+    matrices, then the packed index blob.  `full=False` leaves out the tensors of the reference's batch dict
+    that only the reference's own modules read (`edge_index`, `edge_attr`, `edge_select`, `golden_edge`,
+    `in_piece_edge_idx`): the kernels take everything from `'_native'`."""
+    lib = _lib.lib()
+    B = len(lens)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    total = int((lens.astype(np.int64) ** 2).sum())
+    e_cap = int(np.count_nonzero(ad)) + 1
+    p_cap = total + 1
+    e_src, e_dst, e_type, in_piece = (np.zeros(e_cap, np.int32) for _ in range(4))
+    pg, pm, pn, pgold = (np.zeros(p_cap, np.int32) for _ in range(4))
+    ne, ni, npair = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    version, state, gauss = random.getstate()
+    mt = np.asarray(state, dtype=np.uint32)
+    rc = lib.psvae_collate_pairs(B, N, _ptr(lens), _ptr(ad), _ptr(cross), 2.0 if all_pairs else NEG_RATE, _ptr(mt),
+                                 _ptr(e_src), _ptr(e_dst), _ptr(e_type), e_cap, C.byref(ne),
+                                 _ptr(in_piece), C.byref(ni), _ptr(pg), _ptr(pm), _ptr(pn), _ptr(pgold), p_cap,
+                                 C.byref(npair))
+    _lib.check(rc, 'psvae_collate_pairs')
+    if not all_pairs:
+        random.setstate((version, tuple(mt.tolist()), gauss))
+    ne, ni, npair = ne.value, ni.value, npair.value
+    e_src, e_dst, e_type, in_piece = e_src[:ne], e_dst[:ne], e_type[:ne], in_piece[:ni]
+    pg, pm, pn, pgold = pg[:npair], pm[:npair], pn[:npair], pgold[:npair]
+    L = pieces.shape[1]
+    mask = np.arange(N)[None, :] >= lens[:, None]
+    props_sel = props.reshape(B, -1)[:, list(BPEMolDataset.selected_properties)].float().numpy()
+    native = pack_native(lens, N, L, x, xp, xq, e_src, e_dst, e_type, in_piece, pg, pm, pn, pgold, pieces,
+                         props_sel, tokenizer, BPEMolDataset.max_pos)
+    as64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+    batch = {'x': as64(x), 'x_pieces': as64(xp), 'x_pos': as64(xq), 'atom_mask': torch.from_numpy(mask),
+             'pieces': as64(pieces), 'props': props}
+    if full:
+        sel = np.zeros((B, N, N), dtype=bool)
+        sel[pg, pm, pn] = True
+        onehot = np.zeros((ne, 4), dtype=np.int64)
+        onehot[np.arange(ne), e_type] = 1
+        batch.update({
+            'edge_index': torch.from_numpy(np.stack([e_src, e_dst]).astype(np.int64)) if ne else torch.zeros(2, 0, dtype=torch.long),
+            'edge_attr': torch.from_numpy(onehot), 'edge_select': torch.from_numpy(sel),
+            'golden_edge': torch.from_numpy(pgold.astype(np.int64)), 'in_piece_edge_idx': in_piece.tolist()})
+    dev = torch.device(device)
+    if dev.type != 'cpu':
+        batch = to_device(batch, dev)
+        native = native.to(dev)
+    batch['_native'] = native
+    return batch
+
+
+class PackedMolDataset(torch.utils.data.Dataset):
+    """The same batches as `BPEMolDataset` (bit for bit, including the draws from Python's `random`), for
+    feeding a GPU whose step takes about a millisecond: the records are flattened into a few numpy arrays
+    once, `__getitem__` hands out the index only, and `collate_fn` runs stage 2 and stage 3
+    (`src/data/bpe_dataset.py:56-155`) for the whole batch in native code.  `full=True` also builds the
+    tensors of the reference's batch dict that only the reference's own modules read."""
+
+    def __init__(self, records, tokenizer, full=False):
+        super().__init__()
+        self.tokenizer, self.full = tokenizer, full
+        M = len(records)
+        n_at = np.fromiter((len(r['x']) for r in records), dtype=np.int64, count=M)
+        n_bd = np.fromiter((len(r['edge_attr']) for r in records), dtype=np.int64, count=M)
+        n_pc = np.fromiter((len(r['pieces']) for r in records), dtype=np.int64, count=M)
+        self.atom_off = np.concatenate([[0], np.cumsum(n_at)]).astype(np.int64)
+        self.bond_off = np.concatenate([[0], np.cumsum(n_bd)]).astype(np.int64)
+        self.piece_off = np.concatenate([[0], np.cumsum(n_pc)]).astype(np.int64)
+        tot = int(self.atom_off[-1])
+        self.x_all = np.zeros(tot, np.int32)
+        self.piece_of_atom = np.zeros(tot, np.int32)     # what process_step2 leaves in x_pieces (0 for an atom of no group)
+        self.pos_of_atom = np.zeros(tot, np.int32)       # ... in x_pos
+        self.group_of_atom = np.full(tot, -1, np.int32)
+        self.bond_a = np.zeros(int(self.bond_off[-1]), np.int32)
+        self.bond_b = np.zeros(int(self.bond_off[-1]), np.int32)
+        self.bond_t = np.zeros(int(self.bond_off[-1]), np.int8)
+        self.pieces_all = np.zeros(int(self.piece_off[-1]), np.int32)
+        self.props = np.zeros((M, 3), np.float32)
+        for m, r in enumerate(records):
+            a0, b0, p0 = self.atom_off[m], self.bond_off[m], self.piece_off[m]
+            self.x_all[a0:a0 + n_at[m]] = r['x']
+            if n_bd[m]:
+                ei = np.asarray(r['edge_index'], dtype=np.int32).reshape(-1, 2)
+                self.bond_a[b0:b0 + n_bd[m]], self.bond_b[b0:b0 + n_bd[m]] = ei[:, 0], ei[:, 1]
+                self.bond_t[b0:b0 + n_bd[m]] = r['edge_attr']
+            self.pieces_all[p0:p0 + n_pc[m]] = r['pieces']
+            for pos, group in enumerate(r['groups']):
+                if len(group):
+                    g = np.asarray(group, dtype=np.int64) + a0
+                    self.group_of_atom[g] = pos
+                    self.piece_of_atom[g] = r['pieces'][pos]
+                    self.pos_of_atom[g] = pos
+            self.props[m] = r['props']
+
+    def __len__(self):
+        return len(self.atom_off) - 1
+
+    def __getitem__(self, idx):
+        return int(idx)
+
+    def collate_fn(self, indices, device='cpu', all_pairs=False):
+        lib = _lib.lib()
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        B = len(idx)
+        n_at = self.atom_off[idx + 1] - self.atom_off[idx]
+        N = int(n_at.max())
+        L = int((self.piece_off[idx + 1] - self.piece_off[idx]).max())
+        total = int((n_at ** 2).sum())
+        lens = np.zeros(B, np.int32)
+        x, xp, xq = (np.zeros((B, N), np.int32) for _ in range(3))
+        pieces = np.zeros((B, L), np.int32)
+        ad, cross = np.zeros(total, np.int8), np.zeros(total, np.int8)
+        tok = self.tokenizer
+        rc = lib.psvae_gather_molecules(B, _ptr(idx), _ptr(self.atom_off), _ptr(self.x_all), _ptr(self.piece_of_atom),
+                                        _ptr(self.pos_of_atom), _ptr(self.group_of_atom), _ptr(self.bond_off), _ptr(self.bond_a),
+                                        _ptr(self.bond_b), _ptr(self.bond_t), _ptr(self.piece_off), _ptr(self.pieces_all), N, L,
+                                        tok.atom_pad_idx(), tok.pad_idx(), _ptr(lens), _ptr(x), _ptr(xp), _ptr(xq), _ptr(pieces),
+                                        _ptr(ad), _ptr(cross), total)
+        _lib.check(rc, 'psvae_gather_molecules')
+        props = torch.from_numpy(self.props[idx])
+        return collate_matrices(lens, N, x, xp, xq, ad, cross, pieces, props, tok, device, all_pairs, self.full)
 
 
 def get_dataloader(records, tokenizer, batch_size, shuffle=False, num_workers=4):

@@ -117,3 +117,43 @@ def test_packed_index_blob_is_consistent():
     nb2 = ensure_native(foreign, tok)
     assert torch.equal(nb2.blob, nb.blob) and nb2.offsets == nb.offsets
     assert torch.equal(nb2.props, nb.props) and torch.equal(nb2.denoms, nb.denoms)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_packed_dataset_matches_reference_fixture(case):
+    """The flattened data set + native stage 2/3 against the reference's own batches."""
+    from ps_vae_amd.data import PackedMolDataset
+    g = load_golden(case)
+    tok = Tokenizer.synthetic(g['vocab_size'])
+    ds = PackedMolDataset(g['mols'], tok, full=True)
+    random.seed(g['seed'])
+    batch = ds.collate_fn(list(range(len(g['mols']))))
+    assert_same_batch(batch, g['batch'])
+    assert random.random() == g['next_random']
+
+
+@pytest.mark.parametrize('shape,count,picks', [('zinc', 40, [3, 17, 5, 39, 0, 22, 8]), ('qm9', 64, list(range(63, -1, -3)))])
+def test_packed_dataset_equals_per_item_dataset(shape, count, picks):
+    """Same blob, same dict, same state of `random` as the per-item path, for arbitrary index selections; and
+    the array form of stage 2 equals its list form."""
+    from ps_vae_amd.data import PackedMolDataset
+    tok = Tokenizer.synthetic(50)
+    mols = synth.make_molecules(9, shape, 50, count)
+    mols[1] = dict(mols[1], edge_index=mols[1]['edge_index'] + [mols[1]['edge_index'][0]],
+                   edge_attr=mols[1]['edge_attr'] + [3])           # a duplicate bond: the later type wins
+    ds, per_item = PackedMolDataset(mols, tok, full=True), BPEMolDataset(mols, tok)
+    for a, b in zip([per_item[i] for i in (0, 1)], [BPEMolDataset.process_step2(mols[i], tok) for i in (0, 1)]):
+        for k in ('ad_mat', 'edge_select', 'x_pieces', 'x_pos'):
+            assert np.asarray(a[k]).tolist() == b[k], k
+    for sel in (picks, [1, 0, 2]):
+        random.seed(77)
+        want = per_item.collate_fn([per_item[i] for i in sel])
+        state = random.getstate()
+        random.seed(77)
+        got = ds.collate_fn([ds[i] for i in sel])
+        assert random.getstate() == state
+        assert_same_batch(got, want)
+        assert torch.equal(got['_native'].blob, want['_native'].blob) and got['_native'].offsets == want['_native'].offsets
+        assert torch.equal(got['_native'].props, want['_native'].props) and torch.equal(got['_native'].denoms, want['_native'].denoms)
+    slim = PackedMolDataset(mols, tok).collate_fn(picks)
+    assert 'edge_select' not in slim and slim['x'].shape[0] == len(picks)
