@@ -260,6 +260,8 @@ def main():
         else:
             table[name] = {'us_per_step': ms / args.profile_steps * 1e3, 'launches_per_step': cnt / args.profile_steps,
                            'avg_us': per_launch_us, 'GBs': rate / 1e9}
+    if not classes:
+        raise SystemExit('--profile-steps must be at least 1: the roofline object is measured there')
     dom = max(classes, key=lambda k: classes[k][0])
     dms, dwork, dcnt = classes[dom]
     if dom in FLOP_CLASSES:

@@ -305,7 +305,16 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
     const int c = c4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int i1 = graph_off[b + 1];
-    for (int i = graph_off[b]; i < i1; ++i) acc = add4(acc, ld4(x + (long long)i * ldx + c));
+    // 8 rows in flight per round trip (rows past the end re-read the last one and add 0); summed in row order
+    for (int i = graph_off[b]; i < i1; i += 8) {
+        const int last = i1 - 1;
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ld4(x + (long long)min(i + k, last) * ldx + c);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = add4(acc, i + k <= last ? v[k] : zero);
+    }
     st4(pooled + (long long)b * ldp + c, acc);
 }
 
