@@ -263,14 +263,18 @@ __global__ __launch_bounds__(256) void table_grad_partial_kernel(const TableArgs
         const int c = c0 + tx;
         float s = 0.f;
         if (c < t.D) {
-            int k = ka;
-            for (; k + 4 <= kb; k += 4) {
-                const int j0 = idx[k], j1 = idx[k + 1], j2 = idx[k + 2], j3 = idx[k + 3];
-                const float v0 = src[(long long)j0 * ld + off + c], v1 = src[(long long)j1 * ld + off + c];
-                const float v2 = src[(long long)j2 * ld + off + c], v3 = src[(long long)j3 * ld + off + c];
-                s = (((s + v0) + v1) + v2) + v3;
+            // 8 list entries in flight per round trip (slots past the end re-read the last entry and add 0)
+            for (int k = ka; k < kb; k += 8) {
+                const int last = kb - 1;
+                int j[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) j[u] = idx[min(k + u, last)];
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(long long)j[u] * ld + off + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += k + u <= last ? v[u] : 0.f;
             }
-            for (; k < kb; ++k) s += src[(long long)idx[k] * ld + off + c];
         }
         part[ty][tx] = s;
         __syncthreads();
