@@ -232,7 +232,7 @@ int stacks_edge_grads(hipStream_t st, const Sz& s, const WS& w, const Stack* k, 
 // products run beside the input-gradient chain.  Fork and join are event waits on the
 // caller's stream, so from outside the call still behaves like work on that one stream.
 // Set PSVAE_STREAMS=0 to run everything on the caller's stream.
-struct Lanes { hipStream_t s1, s2; hipEvent_t ev[12]; };
+struct Lanes { hipStream_t s1, s2; hipEvent_t ev[16]; };
 Lanes* get_lanes() {
     static std::mutex mu;
     static Lanes* per_device[64] = {};
@@ -253,7 +253,7 @@ Lanes* get_lanes() {
         if (pe && pe[0] == '1') (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         bool ok = hipStreamCreateWithPriority(&l->s1, hipStreamNonBlocking, greatest) == hipSuccess &&
                   hipStreamCreateWithPriority(&l->s2, hipStreamNonBlocking, least) == hipSuccess;
-        for (int i = 0; ok && i < 12; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < 16; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { delete l; disabled = 1; return nullptr; }
         per_device[dev] = l;
     }
@@ -442,19 +442,22 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     float* dcond = dec_only ? b.d_conds : w.dcond;
     const bool head_adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z &&
                                g.lvar_w == g.mean_w + (size_t)s.Z * s.G && g.lvar_b == g.mean_b + s.Z;
+    // (the weight gradients of these small layers go to lane 2: nothing on the chain waits for them)
+    if (L) PSVAE_TRY(hand_over(st, s2, L->ev[12]));
     if (head_adjacent) {
-        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc2, scf));
         PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
     } else {
-        PSVAE_TRY(linear_bwd_w(st, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, s.Z, s.G, sc, scf));
-        PSVAE_TRY(linear_bwd_w(st, w.dmulv + s.Z, 2 * s.Z, 0, cond, s.G, 0, 1, g.lvar_w, g.lvar_b, s.B, s.Z, s.G, sc, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, s.Z, s.G, sc2, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.dmulv + s.Z, 2 * s.Z, 0, cond, s.G, 0, 1, g.lvar_w, g.lvar_b, s.B, s.Z, s.G, sc2, scf));
         PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 0));
         PSVAE_TRY(linear_bwd_x(st, w.dmulv + s.Z, 2 * s.Z, p.lvar_w, dcond, s.G, s.B, s.Z, s.G, nullptr, 0, 1));
     }
     const int TH = s.te * s.H;
     if (!dec_only) {
+        if (L) PSVAE_TRY(hand_over(st, s2, L->ev[13]));
+        PSVAE_TRY(linear_bwd_w(s2, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc2, scf));
         PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
-        PSVAE_TRY(linear_bwd_w(st, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc, scf));
     }
     // --- GINE stacks: dL/dx_te of the encoder is the broadcast of the last pooled slice
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
