@@ -28,12 +28,12 @@ __global__ __launch_bounds__(256) void vae_head_fwd_kernel(const float* __restri
 // order) and the KL term; gscale[3] = dL/dkl, denoms[2] = B.
 __global__ void vae_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz0,
                                     const float* __restrict__ dz1, const float* __restrict__ dz2,
-                                    const float* __restrict__ gscale, const float* __restrict__ denoms,
+                                    const GScale gscale, const float* __restrict__ denoms,
                                     float* __restrict__ dmulv, int B, int Z) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * Z) return;
     const int b = t / Z, k = t - b * Z;
-    const float gk = gscale[3] / denoms[2];
+    const float gk = gscale_at(gscale, 3) / denoms[2];
     const float m = mulv[(long long)b * 2 * Z + k], raw = mulv[(long long)b * 2 * Z + Z + k];
     float d = dz0[t];
     if (dz1) d += dz1[t];
@@ -44,17 +44,6 @@ __global__ void vae_head_bwd_kernel(const float* __restrict__ mulv, const float*
     const float sgn = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
     dmulv[(long long)b * 2 * Z + k] = dmu;
     dmulv[(long long)b * 2 * Z + Z + k] = -sgn * dlv;
-}
-
-// Upstream gradients of the four loss terms from the gradient of the 6 outputs
-// [pred, rec, piece, edge, kl, total] with total = w[0] pred + w[1] rec + w[2] kl, rec = piece + edge.
-__global__ void make_gscale_kernel(const float* __restrict__ g, float w_pred, float w_rec, float w_kl, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        out[0] = g[0] + g[5] * w_pred;
-        out[1] = g[2] + g[1] + g[5] * w_rec;
-        out[2] = g[3] + g[1] + g[5] * w_rec;
-        out[3] = g[4] + g[5] * w_kl;
-    }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -95,10 +84,10 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(float* __restrict__ logits, int ld,
                                                              const int32_t* __restrict__ target, int tstride, int toffset,
                                                              int rpg, int rows, int classes, int ignore_index,
-                                                             const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                             const float* __restrict__ lse, const GScale gscale,
                                                              int gidx, const float* __restrict__ denoms, int didx) {
     const long long total = (long long)rows * classes;
-    const float scale = gscale[gidx] / denoms[didx];
+    const float scale = gscale_at(gscale, gidx) / denoms[didx];
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(t / classes), c = (int)(t - (long long)r * classes);
         const int tg = ce_target(target, tstride, toffset, rpg, r);
@@ -119,12 +108,12 @@ __global__ void mse_fwd_kernel(const float* __restrict__ pred, int ldp, const fl
     row[b] = s;
 }
 __global__ void mse_bwd_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ gold,
-                               const float* __restrict__ gscale, const float* __restrict__ denoms,
+                               const GScale gscale, const float* __restrict__ denoms,
                                float* __restrict__ dpred, int B, int P) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * P) return;
     const int b = t / P, k = t - b * P;
-    dpred[(long long)b * ldp + k] = 2.0f * (pred[(long long)b * ldp + k] - gold[t]) * gscale[0] / denoms[3];
+    dpred[(long long)b * ldp + k] = 2.0f * (pred[(long long)b * ldp + k] - gold[t]) * gscale_at(gscale, 0) / denoms[3];
 }
 
 // losses = [pred, rec, piece, edge, kl]
@@ -216,7 +205,7 @@ int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, f
     return 0;
 }
 int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
-                 const float* gscale,
+                 GScale gscale,
                  const float* denoms, float* dmulv, int B, int Z) {
     if (B == 0) return 0;
     { ProfScope prof(s, KC_HEAD, 0);
@@ -238,7 +227,7 @@ int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* ta
 }
 int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, const float* lse,
-                   const float* gscale, int gidx, const float* denoms, int didx) {
+                   GScale gscale, int gidx, const float* denoms, int didx) {
     if (rows == 0) return 0;
     long long total = (long long)rows * classes;
     int blocks = (int)((total + 255) / 256);
@@ -258,18 +247,12 @@ int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float*
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
-int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const float* gscale, const float* denoms,
+int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, GScale gscale, const float* denoms,
             float* dpred, int B, int P) {
     if (B == 0) return 0;
     { ProfScope prof(s, KC_HEAD, 0);
     hipLaunchKernelGGL(mse_bwd_kernel, dim3((B * P + 255) / 256), dim3(256), 0, s, pred, ldp, gold, gscale, denoms, dpred, B, P);
     }
-    PSVAE_LAUNCH_CHECK();
-    return 0;
-}
-int make_gscale(hipStream_t s, const float* g6, const float* w3, float* out4) {
-    ProfScope prof(s, KC_HEAD, 0);
-    hipLaunchKernelGGL(make_gscale_kernel, dim3(1), dim3(64), 0, s, g6, w3 ? w3[0] : 0.f, w3 ? w3[1] : 0.f, w3 ? w3[2] : 0.f, out4);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

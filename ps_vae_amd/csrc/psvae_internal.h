@@ -114,21 +114,30 @@ int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_
                  int ldde, float* dz, int dz_accumulate, int n, int B, int H, int Z);
 
 // ------------------------------------------------------------ heads / losses
+// Upstream gradients of the four loss terms [pred, piece, edge, kl], derived inside the consuming kernels from
+// the gradient g[6] (DEVICE) of the step's outputs [pred, rec, piece, edge, kl, total] and the loss weights:
+// total = w_pred pred + w_rec rec + w_kl kl, rec = piece + edge.
+struct GScale { const float* g; float w_pred, w_rec, w_kl; };
+#ifdef __HIPCC__
+__device__ __forceinline__ float gscale_at(const GScale& s, int k) {
+    const float g5 = s.g[5];
+    return k == 0 ? s.g[0] + g5 * s.w_pred : (k == 1 ? s.g[2] + s.g[1] + g5 * s.w_rec : (k == 2 ? s.g[3] + s.g[1] + g5 * s.w_rec : s.g[4] + g5 * s.w_kl));
+}
+#endif
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z);
 int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
-                 const float* gscale,
+                 GScale gscale,
                  const float* denoms, float* dmulv, int B, int Z);
 int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse);
 int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, const float* lse,
-                   const float* gscale, int gidx, const float* denoms, int didx);
+                   GScale gscale, int gidx, const float* denoms, int didx);
 int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float* row, int B, int P);
-int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, const float* gscale, const float* denoms,
+int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, GScale gscale, const float* denoms,
             float* dpred, int B, int P);
 int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* piece_row, int rows_p,
                     const float* edge_row, int S, const float* klrow, const float* denoms, const float* w3, float* losses);
-int make_gscale(hipStream_t s, const float* g6, const float* w3, float* out4);
 int fill_zero(hipStream_t s, float* p, int64_t count);
 // softmax over the 4 bond classes of S pairs: probabilities [S,4], the largest one and its class (any may be null)
 int link_softmax(hipStream_t s, const float* logits, float* probs, float* conf, int32_t* type, int S);

@@ -367,9 +367,8 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
         PSVAE_TRY(fill_zero(s2, w.mse_row, s.B));   // no property head: its loss reads 0
     }
     if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[3])); PSVAE_TRY(hand_over(s2, st, L->ev[4])); }
-    PSVAE_TRY(losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, w.losses));
-    if (hipMemcpyAsync(losses, w.losses, 6 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
-    return 0;
+    // straight into the caller's buffer (a separate 24-byte copy would be one more dependent launch)
+    return losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, losses);
 }
 
 extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
@@ -388,8 +387,9 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     float *sc = w.scratch, *sc1 = w.scratch1, *sc2 = w.scratch2;
     const size_t nH = (size_t)s.n * s.H;
 
-    PSVAE_TRY(make_gscale(st, loss_grads, loss_weights, w.gscale));
-    const float* gs = w.gscale;  // upstream gradients of [pred, piece, edge, kl]
+    // upstream gradients of [pred, piece, edge, kl]: derived inside the kernels that use them
+    const GScale gs{loss_grads, loss_weights ? loss_weights[0] : 0.f, loss_weights ? loss_weights[1] : 0.f,
+                    loss_weights ? loss_weights[2] : 0.f};
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[0])); PSVAE_TRY(hand_over(st, s2, L->ev[1])); }
     // --- lane 1: piece branch (cross-entropy, to_vocab, GRU, latent_to_rnn_hidden)
     PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
