@@ -60,19 +60,34 @@ class _StepFn(torch.autograd.Function):
                                'must be multiples of 4; 4 bond types)')
         ws = torch.empty(nbytes, dtype=torch.uint8, device=eps.device)
         losses = torch.empty(6, dtype=torch.float32, device=eps.device)
+        ctx.set_materialize_grads(False)
         stream = torch.cuda.current_stream().cuda_stream
         w3 = (C.c_float * 3)(*weights)
         _lib.check(L.psvae_step_forward(C.byref(dims), C.byref(params), C.byref(bs), ws.data_ptr(), nbytes,
                                         C.byref(w3), losses.data_ptr(), stream), 'psvae_step_forward')
         ctx.model, ctx.nb, ctx.eps, ctx.ws, ctx.nbytes, ctx.w3 = model, nb, eps, ws, nbytes, w3
         model._last_ws = (ws, nb)
-        return losses
+        # the weighted total is handed out as an output of its own (same storage as losses[5]) so that
+        # `total.backward()` needs no select-backward (a zero fill and a scatter of one number every step)
+        return losses, losses[5]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_total):
         L = _lib.lib()
         model, nb = ctx.model, ctx.nb
-        g = g.contiguous()   # upstream gradients of (pred, rec, piece, edge, kl, total)
+        # upstream gradients of (pred, rec, piece, edge, kl, total) as one device vector
+        if g is None:
+            if model._g6 is None or model._g6.device != ctx.eps.device:
+                model._g6 = torch.zeros(6, dtype=torch.float32, device=ctx.eps.device)
+            g = model._g6
+            if g_total is None:
+                return None, None, None, None, None
+            g[5:6].copy_(g_total.reshape(1))
+        else:
+            g = g.contiguous()
+            if g_total is not None:
+                g = g.clone()
+                g[5] += g_total
         grads_struct, fresh = model._grad_target()
         bs = nb.struct(ctx.eps)
         stream = torch.cuda.current_stream().cuda_stream
@@ -82,7 +97,7 @@ class _StepFn(torch.autograd.Function):
                    'psvae_step_backward')
         model._grad_written(fresh)
         ctx.ws = None
-        return g.new_zeros(()), None, None, None, None
+        return None, None, None, None, None
 
 
 class PSVAEModel(nn.Module):
@@ -105,6 +120,7 @@ class PSVAEModel(nn.Module):
         self._grads_fresh = True
         self._trigger = None
         self._last_ws = None
+        self._g6 = None
         self._dims = self._make_dims()
 
     # ------------------------------------------------------------------ layout
@@ -223,8 +239,7 @@ class PSVAEModel(nn.Module):
             eps = torch.randn(B, self._dims.latent, dtype=torch.float32, device=self._flat.device)
         eps = eps.to(self._flat.device, torch.float32).contiguous()
         alpha = float(self.config['alpha'])
-        out = _StepFn.apply(self._trigger, self, nb, eps, (1.0 - alpha, alpha, float(self.cal_beta())))
-        self._last_total = out[5]
+        out, self._last_total = _StepFn.apply(self._trigger, self, nb, eps, (1.0 - alpha, alpha, float(self.cal_beta())))
         pred_loss, losses = out[0], (out[1], out[2], out[3], out[4])
         if return_accu:
             return pred_loss, (losses, self._accuracies(nb))
