@@ -209,9 +209,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     float* C = p.C + seg * p.seg_c;
     const float bj = p.bias ? p.bias[seg * p.seg_bias + j] : 0.f;
     const float* mask = p.mask ? p.mask + seg * p.seg_mask : nullptr;
+    const int row0 = m0 + wm * 32 + 4 * (lane >> 5);
+    // what the epilogue reads (gate values, the old C when accumulating) is fetched for all 16 rows at once,
+    // from clamped addresses: one memory round trip instead of one per row
+    float gate[16], old[16];
+    if (mask) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            gate[reg] = mask[(long long)min(row0 + (reg & 3) + 8 * (reg >> 2), p.M - 1) * p.ldmask + min(j, p.N - 1)];
+    }
+    if (p.accumulate && j != p.ones_col) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) old[reg] = C[(long long)min(row0 + (reg & 3) + 8 * (reg >> 2), p.M - 1) * p.ldc + j];
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int i = row0 + (reg & 3) + 8 * (reg >> 2);
         if (i >= p.M) continue;
         float v = acc[reg] + bj;
         if (p.relu) v = fmaxf(v, 0.f);
@@ -219,9 +232,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
             if (p.c_extra) p.c_extra[i] = p.accumulate ? p.c_extra[i] + v : v;
             continue;
         }
-        if (mask && !(mask[(long long)i * p.ldmask + j] > 0.f)) v = 0.f;
-        float* dst = C + (long long)i * p.ldc + j;
-        *dst = p.accumulate ? *dst + v : v;
+        if (mask && !(gate[reg] > 0.f)) v = 0.f;
+        C[(long long)i * p.ldc + j] = p.accumulate ? old[reg] + v : v;
     }
 }
 
