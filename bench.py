@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config, synth  # noqa: E402
 from ps_vae_amd import _lib  # noqa: E402
 from ps_vae_amd.data import BPEMolDataset, PackedMolDataset, to_device  # noqa: E402
-from ps_vae_amd.parallel import GradReducer  # noqa: E402
+from ps_vae_amd.parallel import GradReducer, OverlappedReducer  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -166,6 +166,8 @@ def main():
     batches = [to_device(b, dev) for b in cpu_batches]
     model.flat_buffers()
     reducer = GradReducer([0, model._n_trained], always=dist_on)     # one collective for the whole gradient (7.6 MB)
+    # PSVAE_BENCH_OVERLAP=1: two gradient messages, the first one overlapped with the rest of backward
+    overlap = OverlappedReducer(model, always=dist_on) if dist_on and os.environ.get('PSVAE_BENCH_OVERLAP') == '1' else None
     local_denoms = [b['_native'].denoms.clone() for b in batches]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
@@ -193,7 +195,10 @@ def main():
         if dist_on:
             if shared_gpu:
                 torch.cuda.synchronize()
-            reducer.reduce_grads(model.flat_buffers()[1])
+            if overlap is not None:
+                overlap.reduce()
+            else:
+                reducer.reduce_grads(model.flat_buffers()[1])
             if shared_gpu:
                 torch.cuda.synchronize()
             exchange_denoms(i + 1)

@@ -153,6 +153,17 @@ int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const
 int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
                         void* workspace, size_t workspace_bytes, const float* loss_weights,
                         const float* loss_grads, const psvae_params* grads, void* stream);
+/* psvae_step_backward that also tells a data-parallel caller when gradients may leave (no counterpart in the
+ * reference, which has no working multi-GPU path): early_event_1 / early_event_2 (hipEvent_t, either may be
+ * NULL) are recorded on the internal streams once the gradients of, respectively, the piece branch (to_vocab,
+ * GRU, latent_to_rnn_hidden) and the property head + link scorer + W_mean/W_log_var + encoder.linear are
+ * final, i.e. while the GINE stacks' backward is still running.  A caller that keeps the gradient tensors in
+ * that order in one buffer can start the all-reduce of that range on another stream after waiting for both
+ * events, and of the rest after the call's work on `stream`. */
+int psvae_step_backward_signal(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                               void* workspace, size_t workspace_bytes, const float* loss_weights,
+                               const float* loss_grads, const psvae_params* grads, void* stream,
+                               void* early_event_1, void* early_event_2);
 /* Offsets (in floats) of named activations inside the workspace, for tests and
  * the module-level API.  Returns -1 for an unknown name. */
 int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_batch* batch_sizes, const char* name);

@@ -371,9 +371,10 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     return losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, losses);
 }
 
-extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
-                                   void* workspace, size_t workspace_bytes, const float* loss_weights,
-                                   const float* loss_grads, const psvae_params* grads, void* stream) {
+namespace {
+int step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                  void* workspace, size_t workspace_bytes, const float* loss_weights,
+                  const float* loss_grads, const psvae_params* grads, void* stream, hipEvent_t early1, hipEvent_t early2) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !loss_grads || !grads) return PSVAE_E_NULL;
     const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_params& g = *grads; const psvae_batch& b = *batch;
@@ -402,6 +403,7 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     PSVAE_TRY(linear_bwd_w(s1, w.dgh, 3 * s.R, 0, w.hprev, s.R, 0, 1, g.gru_whh, g.gru_bhh, s.BT, 3 * s.R, s.R, sc1, scf));
     PSVAE_TRY(linear_bwd_w(s1, w.dgi, 3 * s.R, 0, w.semb, s.Dp, 0, 1, g.gru_wih, g.gru_bih, s.BT, 3 * s.R, s.Dp, sc1, scf));
     PSVAE_TRY(linear_bwd_w(s1, w.dh0, s.R, 0, w.z, s.Z, 0, 1, g.l2h_w, g.l2h_b, s.B, s.R, s.Z, sc1, scf));
+    if (early1 && hipEventRecord(early1, s1) != hipSuccess) return (int)hipGetLastError();   // piece-branch gradients final
     // --- lane 2: property head
     const bool dec_only = b.conds != nullptr;
     if (dec_only && !b.d_conds) return PSVAE_E_NULL;
@@ -459,6 +461,8 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
         PSVAE_TRY(linear_bwd_w(s2, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc2, scf));
         PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
     }
+    // predictor, scorer, latent head and encoder.linear gradients final (all queued on lane 2 by now)
+    if (early2 && hipEventRecord(early2, s2) != hipSuccess) return (int)hipGetLastError();
     // --- GINE stacks: dL/dx_te of the encoder is the broadcast of the last pooled slice
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
     if (!dec_only) {
@@ -518,6 +522,21 @@ extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* p
     PSVAE_TRY(table_grads(st, tg, 3, w.tg_part, w.tg_part_floats));
     if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[10])); PSVAE_TRY(hand_over(s2, st, L->ev[11])); }
     return 0;
+}
+}  // namespace
+
+extern "C" int psvae_step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                                   void* workspace, size_t workspace_bytes, const float* loss_weights,
+                                   const float* loss_grads, const psvae_params* grads, void* stream) {
+    return step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream, nullptr, nullptr);
+}
+
+extern "C" int psvae_step_backward_signal(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                                          void* workspace, size_t workspace_bytes, const float* loss_weights,
+                                          const float* loss_grads, const psvae_params* grads, void* stream,
+                                          void* early_event_1, void* early_event_2) {
+    return step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
+                         (hipEvent_t)early_event_1, (hipEvent_t)early_event_2);
 }
 
 extern "C" int psvae_encode(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,

@@ -91,9 +91,11 @@ class _StepFn(torch.autograd.Function):
         grads_struct, fresh = model._grad_target()
         bs = nb.struct(ctx.eps)
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(L.psvae_step_backward(C.byref(model._dims), C.byref(model._params_struct), C.byref(bs),
-                                         ctx.ws.data_ptr(), ctx.nbytes, C.byref(ctx.w3), g.data_ptr(),
-                                         C.byref(grads_struct), stream),
+        ev = model._early_events
+        _lib.check(L.psvae_step_backward_signal(C.byref(model._dims), C.byref(model._params_struct), C.byref(bs),
+                                                ctx.ws.data_ptr(), ctx.nbytes, C.byref(ctx.w3), g.data_ptr(),
+                                                C.byref(grads_struct), stream,
+                                                ev[0].cuda_event if ev and fresh else None, ev[1].cuda_event if ev and fresh else None),
                    'psvae_step_backward')
         model._grad_written(fresh)
         ctx.ws = None
@@ -121,6 +123,7 @@ class PSVAEModel(nn.Module):
         self._trigger = None
         self._last_ws = None
         self._g6 = None
+        self._early_events = None
         self._dims = self._make_dims()
 
     # ------------------------------------------------------------------ layout
@@ -197,6 +200,19 @@ class PSVAEModel(nn.Module):
         """(parameters, gradients) as flat fp32 tensors over the trained range."""
         self._sync_flat()
         return self._flat[:self._n_trained], self._gflat
+
+    def early_gradient_events(self):
+        """Two CUDA events that every following backward records as soon as the gradients of the flat range
+        `[0, bucket_bounds[3])` (everything but the GINE stacks, node_trans and the embedding tables) are
+        final, while the rest of backward is still running: a data-parallel caller waits for both on its
+        communication stream and starts that range's all-reduce early (`parallel.GradReducer.reduce_grads_early`).
+        Only the first backward after `zero_grad` writes the flat buffer directly, so only that one signals."""
+        self._sync_flat()
+        if self._early_events is None:
+            self._early_events = (torch.cuda.Event(), torch.cuda.Event())
+            for e in self._early_events:
+                e.record()          # creates the underlying event object
+        return self._early_events
 
     def zero_grad(self, set_to_none=False):
         """Marks the flat gradient buffer as empty: the next backward overwrites it

@@ -71,6 +71,41 @@ class GradReducer:
         return works if async_op else []
 
 
+class OverlappedReducer(GradReducer):
+    """Gradient all-reduce in two messages, the first of them overlapped with backward: the model's backward
+    signals (two events) when the gradients of its flat range `[0, split)` are final, which is before the
+    GINE stacks' backward has run; that range is reduced on a side stream meanwhile, the rest after backward.
+
+        red = OverlappedReducer(model)
+        loss.backward(); red.reduce(); opt.step()
+    """
+
+    def __init__(self, model, group=None, always=False):
+        model.flat_buffers()
+        super().__init__([0, model.bucket_bounds[3], model._n_trained], group, always)
+        self.model = model
+        self.events = model.early_gradient_events()
+        self.comm = torch.cuda.Stream(device=model.flat_buffers()[1].device)
+
+    def reduce(self):
+        """Call after `backward`; returns when both collectives are queued and the current stream waits for them."""
+        if not self.active:
+            return
+        grads = self.model.flat_buffers()[1]
+        lo, mid, hi = self.bounds
+        cur = torch.cuda.current_stream()
+        for e in self.events:
+            self.comm.wait_event(e)
+        with torch.cuda.stream(self.comm):
+            early = self._all_reduce(grads[lo:mid], async_op=True)
+        late = self._all_reduce(grads[mid:hi], async_op=True)       # queued behind backward on the current stream
+        if early is not None:
+            early.wait()            # the side stream waits for the collective ...
+        cur.wait_stream(self.comm)  # ... and the current stream for the side stream
+        if late is not None:
+            late.wait()
+
+
 def global_step_reference(loss_sums_per_rank, counts_per_rank):
     """Host arithmetic of the scheme above (used by the CPU tests): per-rank loss sums and
     counts -> the global mean each rank's scaled losses add up to."""
