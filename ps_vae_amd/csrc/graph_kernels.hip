@@ -433,8 +433,7 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     a.ldx = ldx; a.ldo = ldo; a.n = n; a.H4 = H / 4;
     const long long items = (long long)n * a.H4;
     const long long blocks = (items + 255) / 256;
-    static const long long cap = [] { const char* e = getenv("PSVAE_AGG_BLOCKS"); return e ? atoll(e) : (long long)AGG_FWD_MAX_BLOCKS; }();
-    dim3 grid((unsigned)(blocks < cap ? blocks : cap), ngroups);
+    dim3 grid((unsigned)(blocks < AGG_FWD_MAX_BLOCKS ? blocks : AGG_FWD_MAX_BLOCKS), ngroups);
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += 2.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1);
     ProfScope prof(s, KC_AGG_FWD, bytes);

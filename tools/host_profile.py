@@ -19,7 +19,8 @@ def main():
     torch.manual_seed(2021)
     model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)
     opt = model.configure_optimizers()
-    cpu_batches, _ = bench.make_batches(tok, 300, 'zinc', 128, 4, seed=2021)
+    shape, B = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ('zinc', 128)
+    cpu_batches, _ = bench.make_batches(tok, 300, shape, B, 4, seed=2021)
     batches = [to_device(b, dev) for b in cpu_batches]
     gen = torch.Generator(device=dev).manual_seed(1)
     acc = defaultdict(float)
@@ -39,7 +40,7 @@ def main():
             torch.cuda.synchronize()      # keep the launch queue from filling up and blocking the host
         t = time.perf_counter()
         batch = batches[i % 4]
-        eps = torch.randn(128, 56, device=dev, generator=gen); t = lap('randn', t)
+        eps = torch.randn(B, 56, device=dev, generator=gen); t = lap('randn', t)
         opt.zero_grad(); t = lap('zero_grad', t)
         loss = model.training_step(batch, eps=eps); t = lap('forward', t)
         loss.backward(); t = lap('backward', t)
