@@ -27,7 +27,9 @@ extern "C" int psvae_clip_adam(float* params, float* grads, float* exp_avg, floa
 
 extern "C" size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg) {
     size_t a = gemm_scratch_floats(M, N, K, 1, false);          // forward
-    size_t b = gemm_scratch_floats(N, K + 1, M, nseg, true);     // weight gradient
+    size_t b = gemm_scratch_floats(N, K + 1, M, nseg, true);     // weight gradient with the bias column ...
+    size_t c = gemm_scratch_floats(N, K, M, nseg, true);         // ... and without it (another tile count, another split)
+    if (c > b) b = c;
     return (a > b ? a : b) * sizeof(float) + 256;
 }
 

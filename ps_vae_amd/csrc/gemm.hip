@@ -308,14 +308,19 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
     if (slab) {
         const size_t need = (size_t)(nz_total * (long long)d.M * d.N);
         if (!d.scratch || d.scratch_floats < need) {
-            if (d.sum_segments && d.nseg > 1) {
-                // fall back to one slab per segment if that fits, else give up
-                if (!d.scratch || d.scratch_floats < (size_t)d.nseg * d.M * d.N) return PSVAE_E_WORKSPACE;
+            // a scratch buffer too small for the planned split still gets the largest split that fits
+            const size_t per_split = (size_t)d.nseg * d.M * d.N;
+            const long long fit = d.scratch ? (long long)(d.scratch_floats / per_split) : 0;
+            if (fit >= 2 || (fit >= 1 && d.sum_segments && d.nseg > 1)) {
+                pl.rchunk = (int)round_up((d.R + fit - 1) / fit, BK);
+                pl.splits = (d.R + pl.rchunk - 1) / pl.rchunk;
+            } else if (d.sum_segments && d.nseg > 1) {
+                return PSVAE_E_WORKSPACE;       // summed segments cannot do without their slabs
             } else {
                 slab = false;
+                pl.splits = 1; pl.rchunk = (int)round_up(d.R > 0 ? d.R : 1, BK);
             }
-            pl.splits = 1; pl.rchunk = (int)round_up(d.R > 0 ? d.R : 1, BK);
-            nz_total = d.nseg;
+            nz_total = (long long)d.nseg * pl.splits;
         }
     }
     GemmP p;

@@ -71,6 +71,29 @@ def test_linear_strided_mask_accumulate_and_segments():
     check_close(db, dy_all.sum((0, 1)), 'db over segments')
 
 
+@pytest.mark.parametrize('bias', [True, False])
+@pytest.mark.parametrize('scratch_frac', [1.0, 0.3, 0.0])
+def test_weight_gradient_with_any_scratch_size(bias, scratch_frac):
+    """Weight gradient at tile-aligned sizes, with and without the bias column, with the scratch buffer the
+    size query asks for, a smaller one (a smaller split must be chosen) and none (no split)."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    M, N, K = 5000, 128, 192
+    dy, x = _rand(M, N, seed=21), _rand(M, K, seed=22)
+    d_dy, d_x = dy.to(dev()), x.to(dev())
+    dw = torch.full((N, K), float('nan'), device=dev())
+    db = torch.full((N,), float('nan'), device=dev())
+    nbytes = int(L.psvae_linear_scratch_bytes(M, N, K, 1) * scratch_frac) // 16 * 16
+    sc = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev())
+    _lib.check(L.psvae_linear_backward_weight(d_dy.data_ptr(), N, 0, d_x.data_ptr(), K, 0, 1, dw.data_ptr(),
+                                              db.data_ptr() if bias else None, M, N, K,
+                                              sc.data_ptr() if nbytes else None, nbytes, st))
+    check_close(dw, dy.t() @ x, 'dw', rtol=2e-4, atol_scale=2e-5)
+    if bias:
+        check_close(db, dy.sum(0), 'db', rtol=2e-4, atol_scale=2e-5)
+
+
 def _random_graph(n, E, seed):
     g = torch.Generator().manual_seed(seed)
     ei = torch.randint(0, n, (2, E), generator=g)
