@@ -99,6 +99,68 @@ def cpu_baseline(cpu_batch, qm9_batch, vocab, budget_s=12.0, max_steps=8):
                         'sample': f'{nq} steps on one batch of {Bq} QM9-shape graphs ({dtq / nq * 1e3:.1f} ms/step)'}}
 
 
+def bulk_message_passing(dev, graphs=4096, H=300, iters=40):
+    """The aggregation kernels at the bulk-encoding size (4096 ZINC-shape graphs, about 95 k atoms), where a
+    launch moves a few hundred MB instead of the 7-11 MB of a 128-graph training step and is therefore
+    bound by HBM rather than by launch latency.  Buffers rotate over more than 1 GB so that every launch
+    streams from HBM as it does inside an encoder pass (a single buffer set would sit in the 256 MB
+    last-level cache).  Timed with events on the stream the kernels are launched on; algorithmic bytes as
+    in the per-step classes: forward 2 n 4H + 5E + 4(n+1), backward 3 n 4H + 5E + 4(n+1)."""
+    from ps_vae_amd.ops import Csr
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    base = max(1, graphs // 4)
+    mols = synth.make_molecules(77, 'zinc', 300, base)
+    src, dst, typ, off = [], [], [], 0
+    for m in mols:
+        for (a, b), ty in zip(m['edge_index'], m['edge_attr']):
+            src += [a + off, b + off]; dst += [b + off, a + off]; typ += [ty, ty]
+        off += len(m['x'])
+    reps = graphs // base
+    ei = torch.tensor([src, dst], device=dev)
+    ei = torch.cat([ei + r * off for r in range(reps)], 1)
+    n = off * reps
+    csr = Csr(ei, torch.tensor(typ, device=dev).repeat(reps), n)
+    E = csr.E
+    K = max(2, int(1.2e9 / (3.0 * n * H * 4)) + 1)
+    xs = [torch.randn(n, H, device=dev) for _ in range(K)]
+    das = [torch.randn(n, H, device=dev) for _ in range(K)]
+    outs = [torch.empty(n, H, device=dev) for _ in range(K)]
+    ew, eb = torch.randn(H, 4, device=dev), torch.randn(H, device=dev)
+    part = torch.empty(max(1, L.psvae_gine_edge_grad_scratch(n, H)), device=dev)
+
+    def fwd(k):
+        _lib.check(L.psvae_gine_aggregate_forward(xs[k].data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.etype.data_ptr(),
+                                                  ew.data_ptr(), eb.data_ptr(), 1.0, outs[k].data_ptr(), H, n, H, st))
+
+    def bwd(k):
+        _lib.check(L.psvae_gine_aggregate_backward(das[k].data_ptr(), H, xs[k].data_ptr(), H, csr.rowptr_t.data_ptr(),
+                                                   csr.col_t.data_ptr(), csr.etype_t.data_ptr(), ew.data_ptr(), eb.data_ptr(), 1.0,
+                                                   None, 0, None, outs[k].data_ptr(), H, None, None, part.data_ptr(), n, H, st))
+
+    def copy(k):
+        outs[k].copy_(xs[k])
+
+    def timed(fn):
+        for i in range(K):
+            fn(i)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(iters):
+            fn(i % K)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters * 1e-3
+
+    tf, tb, tc = timed(fwd), timed(bwd), timed(copy)
+    bf, bb = 2.0 * n * 4 * H + 5.0 * E + 4 * (n + 1), 3.0 * n * 4 * H + 5.0 * E + 4 * (n + 1)
+    return {'workload': f'{graphs} ZINC-shape graphs per launch ({n} atoms, {E} directed bonds, hidden {H}), HBM-resident rotating buffers',
+            'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'gine_aggregate_fwd': {'us': tf * 1e6, 'achieved': bf / tf / 1e9, 'frac': bf / tf / 1e9 / HBM_PEAK_GBS},
+            'gine_aggregate_bwd': {'us': tb * 1e6, 'achieved': bb / tb / 1e9, 'frac': bb / tb / 1e9 / HBM_PEAK_GBS},
+            'plain_copy_same_rows': {'us': tc * 1e6, 'achieved': 2.0 * n * 4 * H / tc / 1e9, 'frac': 2.0 * n * 4 * H / tc / 1e9 / HBM_PEAK_GBS}}
+
+
 PMC_FILE = 'profiles/r01_pmc_traffic.json'
 
 
@@ -123,6 +185,7 @@ def main():
     ap.add_argument('--vocab', type=int, default=300)
     ap.add_argument('--shape', default='zinc')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-bulk', action='store_true', help='skip the aggregation kernels at the bulk-encoding size')
     ap.add_argument('--profile-steps', type=int, default=10)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' rehearses the multi-rank "
                     "path on a box with fewer GPUs than ranks (ranks then share devices)")
@@ -299,6 +362,8 @@ def main():
                             'frac': (mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mp_ms else None},
         'kernel_classes': table,
     }
+    if world == 1 and not args.no_bulk:
+        out['message_passing']['bulk'] = bulk_message_passing(dev)
     if world == 1 and not args.no_cpu_baseline:
         qm9, _ = make_batches(tok, args.vocab, 'qm9', 32, 1, seed=7)
         out['cpu_baseline'] = cpu_baseline(cpu_batches[0], qm9[0], args.vocab)

@@ -91,7 +91,7 @@ extern "C" int psvae_segment_pool_forward(const float* x, int ldx, const int32_t
                                           int B, int width, void* stream) {
     if (!x || !graph_off || !pooled) return PSVAE_E_NULL;
     if (B < 0 || width < 4 || ldx < width || ldp < width) return PSVAE_E_SHAPE;
-    return segment_pool_fwd((hipStream_t)stream, x, ldx, graph_off, pooled, ldp, B, width);
+    return segment_pool_fwd((hipStream_t)stream, x, ldx, 0, width, graph_off, pooled, ldp, B, width);
 }
 
 extern "C" size_t psvae_gru_exchange_bytes(int B, int T, int R) {

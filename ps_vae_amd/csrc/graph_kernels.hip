@@ -33,115 +33,195 @@ __device__ __forceinline__ void stage_edge_tab(float* tab, const float* __restri
 struct AggArgs { AggGroup g[2]; int ldx, ldo, n, H4; };
 constexpr int AGG_FWD_MAX_BLOCKS = 1024;   // per group: 4 blocks per CU; larger inputs loop
 
+// Forward aggregation, software-pipelined over a thread's items (node, channel chunk).  An item needs three
+// dependent memory round trips: its CSR row bounds, then the neighbour indices and bond types of its first
+// four edges, then the neighbour rows.  The loop keeps three items in flight, one per stage, so that an
+// iteration issues the row loads of item k, the index loads of item k+1 and the bound loads of item k+2
+// together and pays one round trip instead of three.  Items past the end are clamped to the last one
+// (valid addresses, nothing stored).  Every load is unconditional: slots past a row's end re-read its last
+// edge (or edge 0 for an empty row) with bond type 4, whose table row is -inf, so that their message
+// relu(x + -inf) is exactly 0.  Rows with more than four edges finish in a loop of their own; the sum
+// keeps edge order throughout.
+struct AggIdx { int j0, j1, j2, j3, t0, t1, t2, t3; };
+
+__device__ __forceinline__ AggIdx agg_load_idx(const int32_t* __restrict__ col, const int32_t* __restrict__ etype, int e, int e1, int emax) {
+    // edges e .. e+3 of a row ending at e1; emax = index of the last edge of the whole graph batch (>= 0)
+    const int last = min(max(e1 - 1, e), emax);
+    const int ea = min(e, last), eb = min(e + 1, last), ec = min(e + 2, last), ed = min(e + 3, last);
+    AggIdx r;
+    r.j0 = col[ea]; r.j1 = col[eb]; r.j2 = col[ec]; r.j3 = col[ed];
+    const int ta = etype[ea] & 3, tb = etype[eb] & 3, tc = etype[ec] & 3, td = etype[ed] & 3;
+    r.t0 = e < e1 ? ta : 4; r.t1 = e + 1 < e1 ? tb : 4; r.t2 = e + 2 < e1 ? tc : 4; r.t3 = e + 3 < e1 ? td : 4;
+    return r;
+}
+
+__device__ __forceinline__ float4 agg_msg4(float4 acc, const float* tab, int H, int c, const AggIdx& q,
+                                           float4 x0, float4 x1, float4 x2, float4 x3) {
+    const float4 e0 = *reinterpret_cast<const float4*>(tab + q.t0 * H + c);
+    const float4 e1 = *reinterpret_cast<const float4*>(tab + q.t1 * H + c);
+    const float4 e2 = *reinterpret_cast<const float4*>(tab + q.t2 * H + c);
+    const float4 e3 = *reinterpret_cast<const float4*>(tab + q.t3 * H + c);
+    acc.x += fmaxf(x0.x + e0.x, 0.f); acc.y += fmaxf(x0.y + e0.y, 0.f);
+    acc.z += fmaxf(x0.z + e0.z, 0.f); acc.w += fmaxf(x0.w + e0.w, 0.f);
+    acc.x += fmaxf(x1.x + e1.x, 0.f); acc.y += fmaxf(x1.y + e1.y, 0.f);
+    acc.z += fmaxf(x1.z + e1.z, 0.f); acc.w += fmaxf(x1.w + e1.w, 0.f);
+    acc.x += fmaxf(x2.x + e2.x, 0.f); acc.y += fmaxf(x2.y + e2.y, 0.f);
+    acc.z += fmaxf(x2.z + e2.z, 0.f); acc.w += fmaxf(x2.w + e2.w, 0.f);
+    acc.x += fmaxf(x3.x + e3.x, 0.f); acc.y += fmaxf(x3.y + e3.y, 0.f);
+    acc.z += fmaxf(x3.z + e3.z, 0.f); acc.w += fmaxf(x3.w + e3.w, 0.f);
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) float etab_lds[];
     const AggGroup& g = a.g[blockIdx.y];
     const int H = a.H4 * 4;
     for (int k = threadIdx.x; k < H; k += blockDim.x) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
     stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
-    // a block walks the (node, channel chunk) items with the grid's stride, so the table is staged once per block
-    const long long total = (long long)a.n * a.H4;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(t / a.H4), c = (int)(t - (long long)i * a.H4) * 4;
-        const float4 xi = ld4(g.x + (long long)i * a.ldx + c);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int e1 = g.rowptr[i + 1];
-        // neighbours in groups of 4: all index loads, then all row loads, are issued together (one latency
-        // round trip per group instead of per edge); the sum keeps edge order.  Every load is unconditional
-        // (a load under a branch makes the compiler wait for everything in flight at each join): slots past
-        // the row's end re-read its last edge with bond type 4, whose table row is -inf, so that their
-        // message relu(x + -inf) is exactly 0.
-        for (int e = g.rowptr[i]; e < e1; e += 4) {
-            const int last = e1 - 1;
-            const int eb = min(e + 1, last), ec = min(e + 2, last), ed = min(e + 3, last);
-            const int j0 = g.col[e], j1 = g.col[eb], j2 = g.col[ec], j3 = g.col[ed];
-            const int t0 = g.etype[e] & 3, t1 = e + 1 > last ? 4 : g.etype[eb] & 3;
-            const int t2 = e + 2 > last ? 4 : g.etype[ec] & 3, t3 = e + 3 > last ? 4 : g.etype[ed] & 3;
-            const float4 x0 = ld4(g.x + (long long)j0 * a.ldx + c), x1 = ld4(g.x + (long long)j1 * a.ldx + c);
-            const float4 x2 = ld4(g.x + (long long)j2 * a.ldx + c), x3 = ld4(g.x + (long long)j3 * a.ldx + c);
-            const float4 e0 = *reinterpret_cast<const float4*>(etab_lds + t0 * H + c);
-            const float4 ee1 = *reinterpret_cast<const float4*>(etab_lds + t1 * H + c);
-            const float4 ee2 = *reinterpret_cast<const float4*>(etab_lds + t2 * H + c);
-            const float4 ee3 = *reinterpret_cast<const float4*>(etab_lds + t3 * H + c);
-            acc.x += fmaxf(x0.x + e0.x, 0.f); acc.y += fmaxf(x0.y + e0.y, 0.f);
-            acc.z += fmaxf(x0.z + e0.z, 0.f); acc.w += fmaxf(x0.w + e0.w, 0.f);
-            acc.x += fmaxf(x1.x + ee1.x, 0.f); acc.y += fmaxf(x1.y + ee1.y, 0.f);
-            acc.z += fmaxf(x1.z + ee1.z, 0.f); acc.w += fmaxf(x1.w + ee1.w, 0.f);
-            acc.x += fmaxf(x2.x + ee2.x, 0.f); acc.y += fmaxf(x2.y + ee2.y, 0.f);
-            acc.z += fmaxf(x2.z + ee2.z, 0.f); acc.w += fmaxf(x2.w + ee2.w, 0.f);
-            acc.x += fmaxf(x3.x + ee3.x, 0.f); acc.y += fmaxf(x3.y + ee3.y, 0.f);
-            acc.z += fmaxf(x3.z + ee3.z, 0.f); acc.w += fmaxf(x3.w + ee3.w, 0.f);
+    // 32-bit item arithmetic (the launcher checks n * H/4 < 2^31)
+    // All blocks sweep the items together, one window of gridDim.x * 256 items at a time (HBM sees one moving
+    // front, as in a plain copy).  Inside a window, workgroups are dealt to the 8 XCDs round-robin by block id,
+    // so blocks b, b+8, b+16 ... take neighbouring pieces: a node's neighbours (a few rows away) are then read
+    // by the same XCD, which fetches a row from HBM once and serves the re-reads from its L2.
+    const unsigned H4 = (unsigned)a.H4, stride = gridDim.x * blockDim.x;
+    const unsigned total = (unsigned)a.n * H4;
+    const unsigned per_xcd = gridDim.x / 8, bx = blockIdx.x;
+    const unsigned logical = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
+    const unsigned tfirst = logical * blockDim.x + threadIdx.x;
+    if (tfirst >= total) return;
+    // the edge count is the last row bound; a batch without edges reads its (unused) indices from rowptr[0] = 0
+    const int E = g.rowptr[a.n], emax = max(E - 1, 0);
+    const int32_t* __restrict__ col = E > 0 ? g.col : g.rowptr;
+    const int32_t* __restrict__ etype = E > 0 ? g.etype : g.rowptr;
+    const float* __restrict__ x = g.x;
+    // pipeline fill: bounds of items 0 and 1, indices of item 0
+    int iA = (int)(tfirst / H4), cA = (int)(tfirst - (unsigned)iA * H4) * 4;
+    int eA0 = g.rowptr[iA], eA1 = g.rowptr[iA + 1];
+    const unsigned tB = min(tfirst + stride, total - 1);
+    int iB = (int)(tB / H4), cB = (int)(tB - (unsigned)iB * H4) * 4;
+    int eB0 = g.rowptr[iB], eB1 = g.rowptr[iB + 1];
+    AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
+    for (unsigned t = tfirst; t < total; t += stride) {
+        // stage 3 of item A: its own row and four neighbour rows
+        const float4 xi = ld4(x + (long long)iA * a.ldx + cA);
+        const float4 x0 = ld4(x + (long long)qA.j0 * a.ldx + cA), x1 = ld4(x + (long long)qA.j1 * a.ldx + cA);
+        const float4 x2 = ld4(x + (long long)qA.j2 * a.ldx + cA), x3 = ld4(x + (long long)qA.j3 * a.ldx + cA);
+        // stage 2 of item B, stage 1 of item C
+        const AggIdx qB = agg_load_idx(col, etype, eB0, eB1, emax);
+        const unsigned tC = min(t + 2 * stride, total - 1);
+        const int iC = (int)(tC / H4), cC = (int)(tC - (unsigned)iC * H4) * 4;
+        const int eC0 = g.rowptr[iC], eC1 = g.rowptr[iC + 1];
+        float4 acc = agg_msg4(make_float4(0.f, 0.f, 0.f, 0.f), etab_lds, H, cA, qA, x0, x1, x2, x3);
+        for (int e = eA0 + 4; e < eA1; e += 4) {   // the rare row with more than four edges
+            const AggIdx q = agg_load_idx(col, etype, e, eA1, emax);
+            const float4 y0 = ld4(x + (long long)q.j0 * a.ldx + cA), y1 = ld4(x + (long long)q.j1 * a.ldx + cA);
+            const float4 y2 = ld4(x + (long long)q.j2 * a.ldx + cA), y3 = ld4(x + (long long)q.j3 * a.ldx + cA);
+            acc = agg_msg4(acc, etab_lds, H, cA, q, y0, y1, y2, y3);
         }
-        st4(g.out + (long long)i * a.ldo + c,
+        st4(g.out + (long long)iA * a.ldo + cA,
             make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
+        iA = iB; cA = cB; eA0 = eB0; eA1 = eB1; qA = qB;
+        iB = iC; cB = cC; eB0 = eC0; eB1 = eC1;
     }
 }
 
-struct AggBwdArgs { AggBwdGroup g[2]; int ldda, ldx, lddx, ldp, n, H4, H4b, nps; const int32_t* node_graph; };
+struct AggBwdArgs { AggBwdGroup g[2]; int ldda, ldx, lddx, ldp, n, H4, H4b, nps, passes; const int32_t* node_graph; };
+
+// gate and accumulate up to four out-edges of node j: acc += v, s_type += v with v = da[i] * (x[j] + e(type) > 0)
+__device__ __forceinline__ void agg_bwd_msg4(float4& acc, float4& s0, float4& s1, float4& s2, float4& s3, const float* tab, int H,
+                                             int c, const AggIdx& q, float4 xj, float4 d0, float4 d1, float4 d2, float4 d3) {
+    const float4 dd[4] = {d0, d1, d2, d3};
+    const int tt[4] = {q.t0, q.t1, q.t2, q.t3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // an empty slot has type 4, whose table row is -inf: its gate is closed and v = 0
+        const float4 ee = *reinterpret_cast<const float4*>(tab + tt[k] * H + c);
+        const float4 v = make_float4(xj.x + ee.x > 0.f ? dd[k].x : 0.f, xj.y + ee.y > 0.f ? dd[k].y : 0.f,
+                                     xj.z + ee.z > 0.f ? dd[k].z : 0.f, xj.w + ee.w > 0.f ? dd[k].w : 0.f);
+        acc = add4(acc, v);
+        // per-type sums: s_k += [type == k] * v, one fused multiply-add each (exactly s_k + v or s_k)
+        const float m0 = tt[k] == 0 ? 1.f : 0.f, m1 = tt[k] == 1 ? 1.f : 0.f, m2 = tt[k] == 2 ? 1.f : 0.f, m3 = tt[k] == 3 ? 1.f : 0.f;
+        s0 = make_float4(fmaf(m0, v.x, s0.x), fmaf(m0, v.y, s0.y), fmaf(m0, v.z, s0.z), fmaf(m0, v.w, s0.w));
+        s1 = make_float4(fmaf(m1, v.x, s1.x), fmaf(m1, v.y, s1.y), fmaf(m1, v.z, s1.z), fmaf(m1, v.w, s1.w));
+        s2 = make_float4(fmaf(m2, v.x, s2.x), fmaf(m2, v.y, s2.y), fmaf(m2, v.z, s2.z), fmaf(m2, v.w, s2.w));
+        s3 = make_float4(fmaf(m3, v.x, s3.x), fmaf(m3, v.y, s3.y), fmaf(m3, v.z, s3.z), fmaf(m3, v.w, s3.w));
+    }
+}
 
 // Backward of the aggregation, by SOURCE node: dx[j] = (1+eps) da[j] + sum over out-edges (j -> i) of
 // da[i] * (x[j] + e(type) > 0)  (+ the pooled-gradient broadcast).  The same products, summed per bond
 // type instead of per node, are the gradient of the edge table, so the kernel accumulates those on the
-// way: a block owns AGG_BWD_PASSES * nps consecutive nodes (nps = 256 / H4b node slots, every thread keeps
-// one channel chunk; rows wider than 256 chunks are split over blockIdx.z in pieces of H4b chunks),
-// combines its slots in order through LDS and writes one [4][H] partial per node block.
-__global__ __launch_bounds__(256) void gine_agg_bwd_kernel(const AggBwdArgs a) {
+// way: a block owns passes * nps consecutive nodes (nps = 256 / H4b node slots, every thread keeps one
+// channel chunk and walks the nodes slot, slot + nps, ...; rows wider than 256 chunks are split over
+// blockIdx.z in pieces of H4b chunks), combines its slots in order through LDS and writes one [4][H]
+// partial per node block.  A thread's walk is software-pipelined like the forward kernel's: the rows of
+// node k, the out-edge indices of node k+1 and the CSR bounds of node k+2 are fetched together.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gine_agg_bwd_kernel(const AggBwdArgs a) {
     __shared__ float4 part[4][256];
     extern __shared__ __attribute__((aligned(16))) float etab_lds[];
     const AggBwdGroup& g = a.g[blockIdx.y];
     const int tid = threadIdx.x;
     const int slot = tid / a.H4b, cl = tid - slot * a.H4b, c4 = blockIdx.z * a.H4b + cl, c = c4 * 4;
     const bool lane_on = slot < a.nps && c4 < a.H4;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     const int H = a.H4 * 4;
-    if (g.da) {   // uniform over the block
-        for (int k = tid; k < H; k += 256) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
-        stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
+    // workgroups are dealt to the 8 XCDs round-robin by block id: blocks b, b+8, b+16 ... take neighbouring node
+    // ranges, so a range and the neighbour rows just outside it are read through the same XCD's L2
+    const int per_xcd = gridDim.x / 8, bx = blockIdx.x;
+    const int logical = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
+    const int node0 = logical * a.nps * a.passes, nend = min(a.n, node0 + a.nps * a.passes);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!g.da) {   // uniform over the block: only the pooled-gradient broadcast is written
+        for (int j = node0 + slot; lane_on && j < nend; j += a.nps)
+            st4(g.dx + (long long)j * a.lddx + c, g.dpool ? ld4(g.dpool + (long long)a.node_graph[j] * a.ldp + c) : zero);
+        return;
     }
-    const int node0 = blockIdx.x * a.nps * AGG_BWD_PASSES;
-    for (int pass = 0; pass < AGG_BWD_PASSES; ++pass) {
-        const int j = node0 + pass * a.nps + slot;
-        if (!lane_on || j >= a.n) continue;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.da) {
-            const float4 xj = ld4(g.x + (long long)j * a.ldx + c);
-            const int e1 = g.rowptr_t[j + 1];
-            for (int e = g.rowptr_t[j]; e < e1; e += 4) {   // groups of 4 with unconditional loads, as in the forward kernel
-                const int last = e1 - 1;
-                const int eb = min(e + 1, last), ec = min(e + 2, last), ed = min(e + 3, last);
-                const int i0 = g.col_t[e], i1 = g.col_t[eb], i2 = g.col_t[ec], i3 = g.col_t[ed];
-                const int t0 = g.etype_t[e] & 3, t1 = e + 1 > last ? 4 : g.etype_t[eb] & 3;
-                const int t2 = e + 2 > last ? 4 : g.etype_t[ec] & 3, t3 = e + 3 > last ? 4 : g.etype_t[ed] & 3;
-                const float4 d0 = ld4(g.da + (long long)i0 * a.ldda + c), d1 = ld4(g.da + (long long)i1 * a.ldda + c);
-                const float4 d2 = ld4(g.da + (long long)i2 * a.ldda + c), d3 = ld4(g.da + (long long)i3 * a.ldda + c);
-                const float4 dd[4] = {d0, d1, d2, d3};
-                const int tt[4] = {t0, t1, t2, t3};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // an empty slot has type 4, whose table row is -inf: its gate is closed and v = 0
-                    const float4 ee = *reinterpret_cast<const float4*>(etab_lds + tt[q] * H + c);
-                    const float4 v = make_float4(xj.x + ee.x > 0.f ? dd[q].x : 0.f, xj.y + ee.y > 0.f ? dd[q].y : 0.f,
-                                                 xj.z + ee.z > 0.f ? dd[q].z : 0.f, xj.w + ee.w > 0.f ? dd[q].w : 0.f);
-                    acc = add4(acc, v);
-                    // per-type sums: s_k += [type == k] * v, one fused multiply-add each (exactly s_k + v or s_k)
-                    const float m0 = tt[q] == 0 ? 1.f : 0.f, m1 = tt[q] == 1 ? 1.f : 0.f, m2 = tt[q] == 2 ? 1.f : 0.f, m3 = tt[q] == 3 ? 1.f : 0.f;
-                    s0 = make_float4(fmaf(m0, v.x, s0.x), fmaf(m0, v.y, s0.y), fmaf(m0, v.z, s0.z), fmaf(m0, v.w, s0.w));
-                    s1 = make_float4(fmaf(m1, v.x, s1.x), fmaf(m1, v.y, s1.y), fmaf(m1, v.z, s1.z), fmaf(m1, v.w, s1.w));
-                    s2 = make_float4(fmaf(m2, v.x, s2.x), fmaf(m2, v.y, s2.y), fmaf(m2, v.z, s2.z), fmaf(m2, v.w, s2.w));
-                    s3 = make_float4(fmaf(m3, v.x, s3.x), fmaf(m3, v.y, s3.y), fmaf(m3, v.z, s3.z), fmaf(m3, v.w, s3.w));
-                }
+    for (int k = tid; k < H; k += 256) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
+    stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
+    float4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
+    if (lane_on && node0 + slot < nend) {
+        // the edge count is the last row bound; a batch without edges reads its (unused) indices from rowptr_t[0] = 0
+        const int E = g.rowptr_t[a.n], emax = max(E - 1, 0);
+        const int32_t* __restrict__ col = E > 0 ? g.col_t : g.rowptr_t;
+        const int32_t* __restrict__ etype = E > 0 ? g.etype_t : g.rowptr_t;
+        const bool has_pool = g.dpool != nullptr;
+        const int32_t* __restrict__ ngraph = has_pool ? a.node_graph : g.rowptr_t;   // without a pooled gradient: any readable word
+        const float* __restrict__ pool = has_pool ? g.dpool : g.da;
+        const float* __restrict__ x = g.x;
+        const float* __restrict__ da = g.da;
+        int jA = node0 + slot, jB = min(jA + a.nps, nend - 1);
+        int eA0 = g.rowptr_t[jA], eA1 = g.rowptr_t[jA + 1], gA = has_pool ? ngraph[jA] : 0;
+        int eB0 = g.rowptr_t[jB], eB1 = g.rowptr_t[jB + 1], gB = has_pool ? ngraph[jB] : 0;
+        AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
+        for (int j = jA; j < nend; j += a.nps) {
+            // stage 3 of node A: its own rows, the rows of its four first out-neighbours, its graph's pooled gradient
+            const float4 xj = ld4(x + (long long)jA * a.ldx + c), dj = ld4(da + (long long)jA * a.ldda + c);
+            const float4 d0 = ld4(da + (long long)qA.j0 * a.ldda + c), d1 = ld4(da + (long long)qA.j1 * a.ldda + c);
+            const float4 d2 = ld4(da + (long long)qA.j2 * a.ldda + c), d3 = ld4(da + (long long)qA.j3 * a.ldda + c);
+            const float4 dp = ld4(pool + (long long)gA * a.ldp + c);
+            // stage 2 of node B, stage 1 of node C
+            const AggIdx qB = agg_load_idx(col, etype, eB0, eB1, emax);
+            const int jC = min(j + 2 * a.nps, nend - 1);
+            const int eC0 = g.rowptr_t[jC], eC1 = g.rowptr_t[jC + 1], gC = has_pool ? ngraph[jC] : 0;
+            float4 acc = zero;
+            agg_bwd_msg4(acc, s0, s1, s2, s3, etab_lds, H, c, qA, xj, d0, d1, d2, d3);
+            for (int e = eA0 + 4; e < eA1; e += 4) {   // the rare node with more than four out-edges
+                const AggIdx q = agg_load_idx(col, etype, e, eA1, emax);
+                const float4 y0 = ld4(da + (long long)q.j0 * a.ldda + c), y1 = ld4(da + (long long)q.j1 * a.ldda + c);
+                const float4 y2 = ld4(da + (long long)q.j2 * a.ldda + c), y3 = ld4(da + (long long)q.j3 * a.ldda + c);
+                agg_bwd_msg4(acc, s0, s1, s2, s3, etab_lds, H, c, q, xj, y0, y1, y2, y3);
             }
-            const float4 dj = ld4(g.da + (long long)j * a.ldda + c);
             acc = make_float4(acc.x + g.ope * dj.x, acc.y + g.ope * dj.y, acc.z + g.ope * dj.z, acc.w + g.ope * dj.w);
+            if (has_pool) acc = add4(acc, dp);
+            st4(g.dx + (long long)jA * a.lddx + c, acc);
+            jA = jB; eA0 = eB0; eA1 = eB1; gA = gB; qA = qB;
+            jB = jC; eB0 = eC0; eB1 = eC1; gB = gC;
         }
-        if (g.dpool) acc = add4(acc, ld4(g.dpool + (long long)a.node_graph[j] * a.ldp + c));
-        st4(g.dx + (long long)j * a.lddx + c, acc);
     }
     if (!g.partial) return;   // uniform over the block
     part[0][tid] = s0; part[1][tid] = s1; part[2][tid] = s2; part[3][tid] = s3;
     __syncthreads();
     if (tid < a.H4b && c4 < a.H4) {
-        float* out = g.partial + (long long)blockIdx.x * 16 * a.H4 + c;
+        float* out = g.partial + (long long)logical * 16 * a.H4 + c;
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
             float4 v = part[tp][tid];
@@ -299,14 +379,17 @@ __global__ __launch_bounds__(128) void table_grad_final_kernel(const TableArgs a
     }
 }
 
-// pooled[b, c] = sum over the graph's rows, in row order.
-__global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ x, int ldx,
-                                                           const int32_t* __restrict__ graph_off,
+// pooled[b, c] = sum over the graph's rows, in row order.  The input is a sequence of slices [rows, ldx] that lie
+// `slice_stride` floats apart; slice k supplies the output columns [k * slice_w, (k+1) * slice_w).
+__global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ x, int ldx, long long slice_stride,
+                                                           int slice_w4, const int32_t* __restrict__ graph_off,
                                                            float* __restrict__ pooled, int ldp, int W4) {
     const int b = blockIdx.y;
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 >= W4) return;
     const int c = c4 * 4;
+    const int slice = c4 / slice_w4;
+    x += slice * slice_stride + (c4 - slice * slice_w4) * 4 - c;   // so that x[row * ldx + c] is the element
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int i1 = graph_off[b + 1];
     // 8 rows in flight per round trip (rows past the end re-read the last one and add 0); summed in row order
@@ -432,6 +515,7 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     if (ngroups == 1) a.g[1] = g[0];
     a.ldx = ldx; a.ldo = ldo; a.n = n; a.H4 = H / 4;
     const long long items = (long long)n * a.H4;
+    if (items + 2LL * AGG_FWD_MAX_BLOCKS * 256 >= (1LL << 31)) return PSVAE_E_SHAPE;   // the kernel counts items in 32 bits
     const long long blocks = (items + 255) / 256;
     dim3 grid((unsigned)(blocks < AGG_FWD_MAX_BLOCKS ? blocks : AGG_FWD_MAX_BLOCKS), ngroups);
     double bytes = 0;
@@ -442,9 +526,18 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     return 0;
 }
 
+// A block of the backward kernel owns nps * passes nodes.  Small inputs use 2 passes (many short blocks);
+// larger ones lengthen the walk instead of adding blocks beyond AGG_BWD_MAX_BLOCKS, which also bounds the
+// number of edge-table partials the reduction has to read.
+constexpr int AGG_BWD_MAX_BLOCKS = 1024;
+static int agg_bwd_passes(int n, int H) {
+    const int H4 = H / 4, H4b = H4 < 256 ? (H4 < 1 ? 1 : H4) : 256, nps = 256 / H4b;
+    const long long per_cap = ((long long)n + (long long)nps * AGG_BWD_MAX_BLOCKS - 1) / ((long long)nps * AGG_BWD_MAX_BLOCKS);
+    return (int)(per_cap > 2 ? per_cap : 2);
+}
 int gine_agg_bwd_blocks(int n, int H) {
     const int H4 = H / 4, H4b = H4 < 256 ? (H4 < 1 ? 1 : H4) : 256;
-    const int per = (256 / H4b) * AGG_BWD_PASSES;
+    const int per = (256 / H4b) * agg_bwd_passes(n, H);
     return (n + per - 1) / per;
 }
 
@@ -466,7 +559,7 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     }
     if (ngroups == 1) a.g[1] = g[0];
     a.ldda = ldda; a.ldx = ldx; a.lddx = lddx; a.ldp = ldp; a.n = n; a.H4 = H / 4; a.H4b = a.H4 < 256 ? a.H4 : 256;
-    a.nps = 256 / a.H4b; a.node_graph = node_graph;
+    a.nps = 256 / a.H4b; a.passes = agg_bwd_passes(n, H); a.node_graph = node_graph;
     dim3 grid((unsigned)gine_agg_bwd_blocks(n, H), ngroups, (a.H4 + a.H4b - 1) / a.H4b);
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += g[k].da ? 3.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1) : 2.0 * n * 4 * H;
@@ -546,13 +639,15 @@ int table_grads(hipStream_t s, const TableGradDesc* t, int nt, float* partial, s
     return 0;
 }
 
-int segment_pool_fwd(hipStream_t s, const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
-                     int B, int width) {
+int segment_pool_fwd(hipStream_t s, const float* x, int ldx, int64_t slice_stride, int slice_width,
+                     const int32_t* graph_off, float* pooled, int ldp, int B, int width) {
     if (B == 0) return 0;
-    if (width % 4 || ldx % 4 || ldp % 4 || !aligned16(x) || !aligned16(pooled)) return PSVAE_E_ALIGN;
+    if (width % 4 || ldx % 4 || ldp % 4 || slice_stride % 4 || slice_width % 4 || !aligned16(x) || !aligned16(pooled)) return PSVAE_E_ALIGN;
+    if (slice_width < 4) return PSVAE_E_SHAPE;
     const int W4 = width / 4;
     ProfScope prof(s, KC_POOL, 4.0 * width * (graph_off ? 1 : 1) * (double)B);
-    hipLaunchKernelGGL(segment_pool_kernel, dim3((W4 + 255) / 256, B), dim3(256), 0, s, x, ldx, graph_off, pooled, ldp, W4);
+    hipLaunchKernelGGL(segment_pool_kernel, dim3((W4 + 255) / 256, B), dim3(256), 0, s, x, ldx, (long long)slice_stride, slice_width / 4,
+                       graph_off, pooled, ldp, W4);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

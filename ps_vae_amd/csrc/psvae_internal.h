@@ -83,7 +83,6 @@ struct AggBwdGroup {
     int E;                  // edge count (work accounting only)
     float* partial;         // null, or [gine_agg_bwd_blocks(n,H)][4][H]: per-block sums for the edge-table gradient
 };
-constexpr int AGG_BWD_PASSES = 2;
 int gine_agg_bwd_blocks(int n, int H);
 int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int ldx, int lddx, int ldp,
                  const int32_t* node_graph, int n, int H);
@@ -105,8 +104,9 @@ struct TableGradDesc {
 };
 size_t table_grads_scratch(const TableGradDesc* t, int ntables);
 int table_grads(hipStream_t s, const TableGradDesc* t, int ntables, float* partial, size_t partial_floats);
-int segment_pool_fwd(hipStream_t s, const float* x, int ldx, const int32_t* graph_off, float* pooled, int ldp,
-                     int B, int width);
+// x: slices [rows, ldx] lying slice_stride floats apart, slice k -> output columns [k*slice_width, (k+1)*slice_width)
+int segment_pool_fwd(hipStream_t s, const float* x, int ldx, int64_t slice_stride, int slice_width,
+                     const int32_t* graph_off, float* pooled, int ldp, int B, int width);
 int pair_gather(hipStream_t s, const float* emb, int lde, const float* z, const int32_t* src, const int32_t* dst,
                 const int32_t* graph, float* out, int S, int H, int Z);
 int pair_scatter(hipStream_t s, const float* dpin, int P, const int32_t* by_src_ptr, const int32_t* by_src_idx,

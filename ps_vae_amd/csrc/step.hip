@@ -141,11 +141,12 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
 
 // Forward of 1 or 2 stacks with the same t: node_trans, then t x (aggregate, Linear+ReLU, Linear).
 int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng) {
-    const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
+    const int n = s.n, H = s.H, t = k[0].t;
+    const size_t nH = (size_t)n * H;   // the layer stack is slice-major: [t+1][n][H]
     const int64_t dX = ng == 2 ? k[1].X - k[0].X : 0, dA = ng == 2 ? k[1].A - k[0].A : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
     {   // slice 0 = node_trans(x0)
         GemmDesc d;
-        d.A = w.X0; d.lda = s.Din; d.B = k[0].node_w; d.ldb = s.Din; d.C = k[0].X; d.ldc = ldx;
+        d.A = w.X0; d.lda = s.Din; d.B = k[0].node_w; d.ldb = s.Din; d.C = k[0].X; d.ldc = H;
         d.M = n; d.N = H; d.R = s.Din; d.bias = k[0].node_b; d.nseg = ng;
         if (ng == 2) { d.seg_b = k[1].node_w - k[0].node_w; d.seg_bias = k[1].node_b - k[0].node_b; d.seg_c = dX; }
         d.scratch = w.scratch; d.scratch_floats = w.scratch_floats;
@@ -154,9 +155,9 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
     for (int l = 0; l < t; ++l) {
         AggGroup ag[2];
         for (int q = 0; q < ng; ++q)
-            ag[q] = AggGroup{k[q].X + (size_t)l * H, k[q].A + (size_t)l * n * H, k[q].rowptr, k[q].col, k[q].etype,
+            ag[q] = AggGroup{k[q].X + (size_t)l * nH, k[q].A + (size_t)l * nH, k[q].rowptr, k[q].col, k[q].etype,
                              k[q].edge_w, k[q].edge_b, k[q].ope, k[q].E};
-        PSVAE_TRY(gine_agg_fwd(st, ag, ng, ldx, H, n, H));
+        PSVAE_TRY(gine_agg_fwd(st, ag, ng, H, H, n, H));
         GemmDesc d1;
         d1.A = k[0].A + (size_t)l * n * H; d1.lda = H; d1.B = k[0].w1; d1.ldb = H; d1.C = k[0].Hid + (size_t)l * n * H; d1.ldc = H;
         d1.M = n; d1.N = H; d1.R = H; d1.bias = k[0].b1; d1.relu = 1; d1.nseg = ng;
@@ -164,7 +165,7 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
         d1.scratch = w.scratch; d1.scratch_floats = w.scratch_floats;
         PSVAE_TRY(gemm_f32(st, d1));
         GemmDesc d2;
-        d2.A = k[0].Hid + (size_t)l * n * H; d2.lda = H; d2.B = k[0].w2; d2.ldb = H; d2.C = k[0].X + (size_t)(l + 1) * H; d2.ldc = ldx;
+        d2.A = k[0].Hid + (size_t)l * n * H; d2.lda = H; d2.B = k[0].w2; d2.ldb = H; d2.C = k[0].X + (size_t)(l + 1) * nH; d2.ldc = H;
         d2.M = n; d2.N = H; d2.R = H; d2.bias = k[0].b2; d2.nseg = ng;
         if (ng == 2) { d2.seg_a = dHid; d2.seg_b = k[1].w2 - k[0].w2; d2.seg_bias = k[1].b2 - k[0].b2; d2.seg_c = dX; }
         d2.scratch = w.scratch; d2.scratch_floats = w.scratch_floats;
@@ -185,7 +186,7 @@ static float* etab_region(const Sz& s, const WS& w, int slot) {
 // w.G0[:, q*H:(q+1)*H] and writes the weight gradients of conv.nn and edge_trans.
 int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch& b, const Stack* k, int ng,
                     const float* const* dpool, int g0_slot0, int etab_slot0) {
-    const int n = s.n, H = s.H, t = k[0].t, ldx = (t + 1) * H;
+    const int n = s.n, H = s.H, t = k[0].t;
     const size_t nH = (size_t)n * H, nblk = (size_t)gine_agg_bwd_blocks(n, H);
     const int64_t dG = ng == 2 ? k[1].Gr - k[0].Gr : 0, dDH = ng == 2 ? k[1].DH - k[0].DH : 0;
     const int64_t dDA = ng == 2 ? k[1].DA - k[0].DA : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
@@ -207,11 +208,11 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
         for (int q = 0; q < ng; ++q) {
             float* dx = l > 0 ? k[q].Gr + (size_t)l * nH : w.G0 + (size_t)(g0_slot0 + q) * H;
             const float* dp = (l > 0 && dpool && dpool[q]) ? dpool[q] + (size_t)(l - 1) * H : nullptr;
-            ag[q] = AggBwdGroup{k[q].DA + (size_t)l * nH, k[q].X + (size_t)l * H, dx, k[q].rowptr_t, k[q].col_t,
+            ag[q] = AggBwdGroup{k[q].DA + (size_t)l * nH, k[q].X + (size_t)l * nH, dx, k[q].rowptr_t, k[q].col_t,
                                 k[q].etype_t, k[q].edge_w, k[q].edge_b, k[q].ope, dp, k[q].E,
                                 etab_region(s, w, etab_slot0 + q) + (size_t)l * nblk * 4 * H};
         }
-        PSVAE_TRY(gine_agg_bwd(st, ag, ng, H, ldx, l > 0 ? H : 2 * H, t * H, b.node_graph, n, H));
+        PSVAE_TRY(gine_agg_bwd(st, ag, ng, H, H, l > 0 ? H : 2 * H, t * H, b.node_graph, n, H));
     }
     return 0;
 }
@@ -290,7 +291,7 @@ int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, 
         if (with_decoder_stack) PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1));
     }
     if (!b.conds) {
-        PSVAE_TRY(segment_pool_fwd(st, w.XE + s.H, (s.te + 1) * s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
+        PSVAE_TRY(segment_pool_fwd(st, w.XE + (size_t)s.n * s.H, s.H, (int64_t)s.n * s.H, s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
         PSVAE_TRY(linear_fwd(st, w.pooled, s.te * s.H, p.enc_lin_w, p.enc_lin_b, w.cond, s.G, s.B, s.G, s.te * s.H, 0,
                              w.scratch, w.scratch_floats));
     }
@@ -345,7 +346,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[1])); PSVAE_TRY(hand_over(st, s2, L->ev[2])); }
     // (the scorer, the longest of the three branches, is queued first)
     // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
-    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
+    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.n * s.H, s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
     PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));
@@ -571,7 +572,7 @@ extern "C" int psvae_score_links(const psvae_dims* dims, const psvae_params* par
     const Stack k = dec_stack(d, p, nullptr, b, w);
     PSVAE_TRY(stacks_forward(st, s, w, &k, 1));
     if (s.S == 0) return 0;
-    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.H, (s.td + 1) * s.H, z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
+    PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.n * s.H, s.H, z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
     PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));

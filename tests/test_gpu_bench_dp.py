@@ -17,7 +17,7 @@ def test_bench_two_ranks_over_gloo():
     env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--backend', 'gloo', '--no-cpu-baseline', '--profile-steps', '1']
+           '--backend', 'gloo', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
@@ -34,7 +34,7 @@ def test_bench_collectives_over_rccl_with_one_rank():
     all-reduce of the denominators) with the one rank a single-GPU box allows."""
     env = dict(os.environ, PSVAE_BENCH_FORCE_DIST='1', PSVAE_BENCH_WATCHDOG='200', MASTER_ADDR='127.0.0.1',
                MASTER_PORT='29537', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-bulk',
            '--profile-steps', '1']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -45,7 +45,7 @@ def test_bench_collectives_over_rccl_with_one_rank():
 def _run(env_extra, ranks, backend, port):
     env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200', **env_extra)
     tail = [os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6', '--warmup', '2', '--backend', backend,
-            '--no-cpu-baseline', '--profile-steps', '1']
+            '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1']
     if ranks > 1:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
                '127.0.0.1', '--master-port', str(port)] + tail

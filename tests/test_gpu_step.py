@@ -61,12 +61,12 @@ def compare_forward_backward(model, d, sd, ref_batch, batch, eps, with_fp64=Fals
     n, B, S, L = (nb.sizes[k] for k in ('n', 'B', 'S', 'L'))
     H, te, td, T = d['hidden'], d['t_enc'], d['t_dec'], L - 1
     mask = ref_batch['atom_mask']
-    enc = model.activation('enc_stack', n, (te + 1) * H)
-    dec = model.activation('dec_stack', n, (td + 1) * H)
+    enc = model.activation('enc_stack', (te + 1) * n, H)      # slice-major: [t+1][n][H]
+    dec = model.activation('dec_stack', (td + 1) * n, H)
     for l in range(te + 1):
-        check_close(enc[:, l * H:(l + 1) * H], unpad(keep['enc_layers'][l], mask), f'encoder layer stack slice {l}')
+        check_close(enc[l * n:(l + 1) * n], unpad(keep['enc_layers'][l], mask), f'encoder layer stack slice {l}')
     for l in range(td + 1):
-        check_close(dec[:, l * H:(l + 1) * H], unpad(keep['dec_layers'][l], mask), f'decoder layer stack slice {l}')
+        check_close(dec[l * n:(l + 1) * n], unpad(keep['dec_layers'][l], mask), f'decoder layer stack slice {l}')
     check_close(model.activation('x0', n, d['d_atom'] + d['d_piece'] + d['d_pos']), unpad(keep['x0'].flatten(0, 1), mask), 'x0')
     check_close(model.activation('pooled', B, te * H), keep['pooled'], 'pooled')
     check_close(model.activation('cond', B, d['graph']), keep['cond'], 'cond')

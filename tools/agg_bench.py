@@ -13,7 +13,11 @@ from ps_vae_amd.ops import Csr  # noqa: E402
 from ps_vae_amd.synth import make_molecules  # noqa: E402
 
 
-def timeit(fn, iters=200):
+ITERS = 200
+
+
+def timeit(fn, iters=None):
+    iters = iters or ITERS
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
@@ -27,11 +31,19 @@ def timeit(fn, iters=200):
 
 
 def main():
+    """Buffers rotate over enough copies to exceed the 256 MB last-level cache several times, so every launch
+    streams from HBM as it does inside an encoder pass (one fixed buffer set of 2 x 114 MB would be served from
+    that cache and flatter the kernels by 1.5x)."""
     L = _lib.lib()
     dev = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
-    H, t = 300, 4
-    for B in (128, 1024, 4096):
+    H = 300
+    global ITERS
+    sizes = [int(v) for v in sys.argv[1:] if v.isdigit()] or [128, 1024, 4096]
+    for v in sys.argv[1:]:
+        if v.startswith('--iters='):
+            ITERS = int(v.split('=')[1])
+    for B in sizes:
         mols = make_molecules(2021, 'zinc', 300, B)
         src, dst, typ, off = [], [], [], 0
         for m in mols:
@@ -40,29 +52,38 @@ def main():
             off += len(m['x'])
         n, E = off, len(src)
         csr = Csr(torch.tensor([src, dst], device=dev), torch.tensor(typ, device=dev), n)
-        stack = torch.randn(n, (t + 1) * H, device=dev)
-        x = stack[:, :H]
-        out = torch.empty(n, H, device=dev)
+        K = max(2, int(1.2e9 / (3.0 * n * H * 4)) + 1)      # buffer sets in rotation: > 1.2 GB in total
+        xs = [torch.randn(n, H, device=dev) for _ in range(K)]
+        outs = [torch.empty(n, H, device=dev) for _ in range(K)]
+        das = [torch.randn(n, H, device=dev) for _ in range(K)]
         ew, eb = torch.randn(H, 4, device=dev), torch.randn(H, device=dev)
-        da, dx = torch.randn(n, H, device=dev), torch.empty(n, H, device=dev)
-        dw, db = torch.zeros(H, 4, device=dev), torch.zeros(H, device=dev)
         part = torch.empty(max(1, L.psvae_gine_edge_grad_scratch(n, H)), device=dev)
-        f = timeit(lambda: L.psvae_gine_aggregate_forward(x.data_ptr(), (t + 1) * H, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                                          csr.etype.data_ptr(), ew.data_ptr(), eb.data_ptr(), 1.0, out.data_ptr(), H, n, H, st))
-        b = timeit(lambda: L.psvae_gine_aggregate_backward(da.data_ptr(), H, x.data_ptr(), (t + 1) * H, csr.rowptr_t.data_ptr(),
-                                                           csr.col_t.data_ptr(), csr.etype_t.data_ptr(), ew.data_ptr(), eb.data_ptr(), 1.0,
-                                                           None, 0, None, dx.data_ptr(), H, None, None, part.data_ptr(), n, H, st))
-        c = timeit(lambda: out.copy_(da))
-        xd = x.contiguous()
-        f_dense = timeit(lambda: L.psvae_gine_aggregate_forward(xd.data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                                                csr.etype.data_ptr(), ew.data_ptr(), eb.data_ptr(), 1.0, out.data_ptr(), H, n, H, st))
-        empty = Csr(torch.zeros(2, 0, dtype=torch.long, device=dev), torch.zeros(0, dtype=torch.long, device=dev), n)
-        f_empty = timeit(lambda: L.psvae_gine_aggregate_forward(xd.data_ptr(), H, empty.rowptr.data_ptr(), empty.col.data_ptr(),
-                                                                empty.etype.data_ptr(), ew.data_ptr(), eb.data_ptr(), 1.0, out.data_ptr(), H, n, H, st))
-        print(f'   fwd dense x {f_dense:6.1f}us | fwd no edges {f_empty:6.1f}us')
+        it = [0]
+
+        def fwd():
+            k = it[0] = (it[0] + 1) % K
+            L.psvae_gine_aggregate_forward(xs[k].data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.etype.data_ptr(),
+                                           ew.data_ptr(), eb.data_ptr(), 1.0, outs[k].data_ptr(), H, n, H, st)
+
+        def bwd():
+            k = it[0] = (it[0] + 1) % K
+            L.psvae_gine_aggregate_backward(das[k].data_ptr(), H, xs[k].data_ptr(), H, csr.rowptr_t.data_ptr(),
+                                            csr.col_t.data_ptr(), csr.etype_t.data_ptr(), ew.data_ptr(), eb.data_ptr(), 1.0,
+                                            None, 0, None, outs[k].data_ptr(), H, None, None, part.data_ptr(), n, H, st)
+
+        def copy():
+            k = it[0] = (it[0] + 1) % K
+            outs[k].copy_(xs[k])
+
+        def copy2():
+            k = it[0] = (it[0] + 1) % K
+            torch.add(xs[k], das[k], out=outs[k])
+
+        f, b, c, c2 = timeit(fwd), timeit(bwd), timeit(copy), timeit(copy2)
         fb, bb = 2.0 * n * 4 * H + 5.0 * E + 4 * (n + 1), 3.0 * n * 4 * H + 5.0 * E + 4 * (n + 1)
-        print(f'B={B} n={n} E={E}: fwd {f:6.1f}us {fb / f / 1e3:6.0f} GB/s | bwd {b:6.1f}us {bb / b / 1e3:6.0f} GB/s | '
-              f'copy [n,H] {c:6.1f}us {2.0 * n * 4 * H / c / 1e3:6.0f} GB/s', flush=True)
+        print(f'B={B} n={n} E={E} ({K} buffer sets): fwd {f:6.1f}us {fb / f / 1e3:6.0f} GB/s | bwd {b:6.1f}us {bb / b / 1e3:6.0f} GB/s | '
+              f'copy [n,H] {c:6.1f}us {2.0 * n * 4 * H / c / 1e3:6.0f} GB/s | a+b [n,H] {c2:6.1f}us {3.0 * n * 4 * H / c2 / 1e3:6.0f} GB/s',
+              flush=True)
 
 
 if __name__ == '__main__':
