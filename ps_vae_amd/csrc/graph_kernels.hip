@@ -14,6 +14,18 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Row (r, float column c) of a matrix with a row pitch of ldb BYTES, addressed as a uniform base plus a 32-bit
+// byte offset: one 24-bit multiply-add per address and the scalar-base form of the load, instead of a
+// 64-bit multiply and add per row.  Needs rows * pitch < 4 GB and rows, pitch < 2^24 (the launchers check).
+__device__ __forceinline__ float4 ld4r(const float* base, int r, unsigned ldb, int c) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (__umul24((unsigned)r, ldb) + (unsigned)c * 4u));
+}
+__device__ __forceinline__ void st4r(float* base, int r, unsigned ldb, int c, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + (__umul24((unsigned)r, ldb) + (unsigned)c * 4u)) = v;
+}
+__device__ __forceinline__ int ldi(const int32_t* base, int k) {   // base[k], k >= 0, as base + 32-bit byte offset
+    return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + (unsigned)k * 4u);
+}
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // Edge term e[type][channel] = edge_w[channel*4 + type] + edge_b[channel] (edge_trans applied to a one-hot),
@@ -31,7 +43,7 @@ __device__ __forceinline__ void stage_edge_tab(float* tab, const float* __restri
 }
 
 struct AggArgs { AggGroup g[2]; int ldx, ldo, n, H4; };
-constexpr int AGG_FWD_MAX_BLOCKS = 1024;   // per group: 4 blocks per CU; larger inputs loop
+constexpr int AGG_FWD_MAX_BLOCKS = 768;   // per group: 3 blocks per CU; larger inputs loop (more blocks in flight measured slower)
 
 // Forward aggregation, software-pipelined over a thread's items (node, channel chunk).  An item needs three
 // dependent memory round trips: its CSR row bounds, then the neighbour indices and bond types of its first
@@ -49,8 +61,8 @@ __device__ __forceinline__ AggIdx agg_load_idx(const int32_t* __restrict__ col, 
     const int last = min(max(e1 - 1, e), emax);
     const int ea = min(e, last), eb = min(e + 1, last), ec = min(e + 2, last), ed = min(e + 3, last);
     AggIdx r;
-    r.j0 = col[ea]; r.j1 = col[eb]; r.j2 = col[ec]; r.j3 = col[ed];
-    const int ta = etype[ea] & 3, tb = etype[eb] & 3, tc = etype[ec] & 3, td = etype[ed] & 3;
+    r.j0 = ldi(col, ea); r.j1 = ldi(col, eb); r.j2 = ldi(col, ec); r.j3 = ldi(col, ed);
+    const int ta = ldi(etype, ea) & 3, tb = ldi(etype, eb) & 3, tc = ldi(etype, ec) & 3, td = ldi(etype, ed) & 3;
     r.t0 = e < e1 ? ta : 4; r.t1 = e + 1 < e1 ? tb : 4; r.t2 = e + 2 < e1 ? tc : 4; r.t3 = e + 3 < e1 ? td : 4;
     return r;
 }
@@ -94,32 +106,33 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     const int32_t* __restrict__ col = E > 0 ? g.col : g.rowptr;
     const int32_t* __restrict__ etype = E > 0 ? g.etype : g.rowptr;
     const float* __restrict__ x = g.x;
+    const unsigned ldxb = (unsigned)a.ldx * 4u, ldob = (unsigned)a.ldo * 4u;
     // pipeline fill: bounds of items 0 and 1, indices of item 0
     int iA = (int)(tfirst / H4), cA = (int)(tfirst - (unsigned)iA * H4) * 4;
-    int eA0 = g.rowptr[iA], eA1 = g.rowptr[iA + 1];
+    int eA0 = ldi(g.rowptr, iA), eA1 = ldi(g.rowptr, iA + 1);
     const unsigned tB = min(tfirst + stride, total - 1);
     int iB = (int)(tB / H4), cB = (int)(tB - (unsigned)iB * H4) * 4;
-    int eB0 = g.rowptr[iB], eB1 = g.rowptr[iB + 1];
+    int eB0 = ldi(g.rowptr, iB), eB1 = ldi(g.rowptr, iB + 1);
     AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
     for (unsigned t = tfirst; t < total; t += stride) {
         // stage 3 of item A: its own row and four neighbour rows
-        const float4 xi = ld4(x + (long long)iA * a.ldx + cA);
-        const float4 x0 = ld4(x + (long long)qA.j0 * a.ldx + cA), x1 = ld4(x + (long long)qA.j1 * a.ldx + cA);
-        const float4 x2 = ld4(x + (long long)qA.j2 * a.ldx + cA), x3 = ld4(x + (long long)qA.j3 * a.ldx + cA);
+        const float4 xi = ld4r(x, iA, ldxb, cA);
+        const float4 x0 = ld4r(x, qA.j0, ldxb, cA), x1 = ld4r(x, qA.j1, ldxb, cA);
+        const float4 x2 = ld4r(x, qA.j2, ldxb, cA), x3 = ld4r(x, qA.j3, ldxb, cA);
         // stage 2 of item B, stage 1 of item C
         const AggIdx qB = agg_load_idx(col, etype, eB0, eB1, emax);
         const unsigned tC = min(t + 2 * stride, total - 1);
         const int iC = (int)(tC / H4), cC = (int)(tC - (unsigned)iC * H4) * 4;
-        const int eC0 = g.rowptr[iC], eC1 = g.rowptr[iC + 1];
+        const int eC0 = ldi(g.rowptr, iC), eC1 = ldi(g.rowptr, iC + 1);
         float4 acc = agg_msg4(make_float4(0.f, 0.f, 0.f, 0.f), etab_lds, H, cA, qA, x0, x1, x2, x3);
         for (int e = eA0 + 4; e < eA1; e += 4) {   // the rare row with more than four edges
             const AggIdx q = agg_load_idx(col, etype, e, eA1, emax);
-            const float4 y0 = ld4(x + (long long)q.j0 * a.ldx + cA), y1 = ld4(x + (long long)q.j1 * a.ldx + cA);
-            const float4 y2 = ld4(x + (long long)q.j2 * a.ldx + cA), y3 = ld4(x + (long long)q.j3 * a.ldx + cA);
+            const float4 y0 = ld4r(x, q.j0, ldxb, cA), y1 = ld4r(x, q.j1, ldxb, cA);
+            const float4 y2 = ld4r(x, q.j2, ldxb, cA), y3 = ld4r(x, q.j3, ldxb, cA);
             acc = agg_msg4(acc, etab_lds, H, cA, q, y0, y1, y2, y3);
         }
-        st4(g.out + (long long)iA * a.ldo + cA,
-            make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
+        st4r(g.out, iA, ldob, cA,
+             make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
         iA = iB; cA = cB; eA0 = eB0; eA1 = eB1; qA = qB;
         iB = iC; cB = cC; eB0 = eC0; eB1 = eC1;
     }
@@ -188,31 +201,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
         const float* __restrict__ pool = has_pool ? g.dpool : g.da;
         const float* __restrict__ x = g.x;
         const float* __restrict__ da = g.da;
+        const unsigned ldxb = (unsigned)a.ldx * 4u, lddab = (unsigned)a.ldda * 4u, lddxb = (unsigned)a.lddx * 4u, ldpb = (unsigned)a.ldp * 4u;
         int jA = node0 + slot, jB = min(jA + a.nps, nend - 1);
-        int eA0 = g.rowptr_t[jA], eA1 = g.rowptr_t[jA + 1], gA = has_pool ? ngraph[jA] : 0;
-        int eB0 = g.rowptr_t[jB], eB1 = g.rowptr_t[jB + 1], gB = has_pool ? ngraph[jB] : 0;
+        int eA0 = ldi(g.rowptr_t, jA), eA1 = ldi(g.rowptr_t, jA + 1), gA = has_pool ? ldi(ngraph, jA) : 0;
+        int eB0 = ldi(g.rowptr_t, jB), eB1 = ldi(g.rowptr_t, jB + 1), gB = has_pool ? ldi(ngraph, jB) : 0;
         AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
         for (int j = jA; j < nend; j += a.nps) {
             // stage 3 of node A: its own rows, the rows of its four first out-neighbours, its graph's pooled gradient
-            const float4 xj = ld4(x + (long long)jA * a.ldx + c), dj = ld4(da + (long long)jA * a.ldda + c);
-            const float4 d0 = ld4(da + (long long)qA.j0 * a.ldda + c), d1 = ld4(da + (long long)qA.j1 * a.ldda + c);
-            const float4 d2 = ld4(da + (long long)qA.j2 * a.ldda + c), d3 = ld4(da + (long long)qA.j3 * a.ldda + c);
-            const float4 dp = ld4(pool + (long long)gA * a.ldp + c);
+            const float4 xj = ld4r(x, jA, ldxb, c), dj = ld4r(da, jA, lddab, c);
+            const float4 d0 = ld4r(da, qA.j0, lddab, c), d1 = ld4r(da, qA.j1, lddab, c);
+            const float4 d2 = ld4r(da, qA.j2, lddab, c), d3 = ld4r(da, qA.j3, lddab, c);
+            const float4 dp = ld4r(pool, gA, ldpb, c);
             // stage 2 of node B, stage 1 of node C
             const AggIdx qB = agg_load_idx(col, etype, eB0, eB1, emax);
             const int jC = min(j + 2 * a.nps, nend - 1);
-            const int eC0 = g.rowptr_t[jC], eC1 = g.rowptr_t[jC + 1], gC = has_pool ? ngraph[jC] : 0;
+            const int eC0 = ldi(g.rowptr_t, jC), eC1 = ldi(g.rowptr_t, jC + 1), gC = has_pool ? ldi(ngraph, jC) : 0;
             float4 acc = zero;
             agg_bwd_msg4(acc, s0, s1, s2, s3, etab_lds, H, c, qA, xj, d0, d1, d2, d3);
             for (int e = eA0 + 4; e < eA1; e += 4) {   // the rare node with more than four out-edges
                 const AggIdx q = agg_load_idx(col, etype, e, eA1, emax);
-                const float4 y0 = ld4(da + (long long)q.j0 * a.ldda + c), y1 = ld4(da + (long long)q.j1 * a.ldda + c);
-                const float4 y2 = ld4(da + (long long)q.j2 * a.ldda + c), y3 = ld4(da + (long long)q.j3 * a.ldda + c);
+                const float4 y0 = ld4r(da, q.j0, lddab, c), y1 = ld4r(da, q.j1, lddab, c);
+                const float4 y2 = ld4r(da, q.j2, lddab, c), y3 = ld4r(da, q.j3, lddab, c);
                 agg_bwd_msg4(acc, s0, s1, s2, s3, etab_lds, H, c, q, xj, y0, y1, y2, y3);
             }
             acc = make_float4(acc.x + g.ope * dj.x, acc.y + g.ope * dj.y, acc.z + g.ope * dj.z, acc.w + g.ope * dj.w);
             if (has_pool) acc = add4(acc, dp);
-            st4(g.dx + (long long)jA * a.lddx + c, acc);
+            st4r(g.dx, jA, lddxb, c, acc);
             jA = jB; eA0 = eB0; eA1 = eB1; gA = gB; qA = qB;
             jB = jC; eB0 = eC0; eB1 = eC1; gB = gC;
         }
@@ -516,6 +530,8 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     a.ldx = ldx; a.ldo = ldo; a.n = n; a.H4 = H / 4;
     const long long items = (long long)n * a.H4;
     if (items + 2LL * AGG_FWD_MAX_BLOCKS * 256 >= (1LL << 31)) return PSVAE_E_SHAPE;   // the kernel counts items in 32 bits
+    // ... and addresses rows by 32-bit byte offsets built with 24-bit multiplies
+    if (n >= (1 << 24) || ldx >= (1 << 22) || ldo >= (1 << 22) || (long long)n * ldx >= (1LL << 30) || (long long)n * ldo >= (1LL << 30)) return PSVAE_E_SHAPE;
     const long long blocks = (items + 255) / 256;
     dim3 grid((unsigned)(blocks < AGG_FWD_MAX_BLOCKS ? blocks : AGG_FWD_MAX_BLOCKS), ngroups);
     double bytes = 0;
@@ -546,6 +562,10 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     if (n == 0) return 0;
     if (H % 4 || ldda % 4 || ldx % 4 || lddx % 4 || ldp % 4) return PSVAE_E_ALIGN;
     if (ngroups < 1 || ngroups > 2 || H < 4) return PSVAE_E_SHAPE;
+    {   // the kernel addresses rows by 32-bit byte offsets built with 24-bit multiplies
+        const int ldmax = ldda > ldx ? (ldda > lddx ? ldda : lddx) : (ldx > lddx ? ldx : lddx);
+        if (n >= (1 << 24) || ldmax >= (1 << 22) || ldp >= (1 << 22) || (long long)n * ldmax >= (1LL << 30)) return PSVAE_E_SHAPE;
+    }
     bool need_tab = false;
     for (int k = 0; k < ngroups; ++k) need_tab = need_tab || g[k].da != nullptr;
     if (need_tab && H > 2048) return PSVAE_E_SHAPE;   // the edge table sits in LDS (20 bytes per channel) beside the partials
