@@ -38,9 +38,10 @@ def make_batches(tok, vocab, shape, batch_size, count, seed, host_times=None):
     what one DataLoader worker pays per batch on the two host paths: stage 2 + 3 per item
     (`BPEMolDataset`) and the flattened data set with both stages native (`PackedMolDataset`)."""
     random.seed(seed)
-    out, t_collate, t_item, t_packed = [], 0.0, 0.0, 0.0
+    out, t_collate, t_item, t_packed, all_mols = [], 0.0, 0.0, 0.0, []
     for i in range(count):
         mols = synth.make_molecules(seed * 1000 + i, shape, vocab, batch_size)
+        all_mols += mols
         t0 = time.perf_counter()
         step2 = [BPEMolDataset.process_step2(m, tok, lists=False) for m in mols]
         t1 = time.perf_counter()
@@ -56,7 +57,7 @@ def make_batches(tok, vocab, shape, batch_size, count, seed, host_times=None):
             t_packed += time.perf_counter() - t3
             random.setstate(state)
     if host_times is not None:
-        host_times.update(per_item_ms=t_item / count * 1e3, packed_ms=t_packed / count * 1e3)
+        host_times.update(per_item_ms=t_item / count * 1e3, packed_ms=t_packed / count * 1e3, mols=all_mols)
     return out, t_collate / count
 
 
@@ -97,6 +98,23 @@ def cpu_baseline(cpu_batch, qm9_batch, vocab, budget_s=12.0, max_steps=8):
                       f'({dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU)',
             'qm9_b32': {'value': Bq * nq / dtq, 'unit': 'molecules/s',
                         'sample': f'{nq} steps on one batch of {Bq} QM9-shape graphs ({dtq / nq * 1e3:.1f} ms/step)'}}
+
+
+def device_collate_ms(mols, tok, dev, batch_size, iters=20):
+    """Milliseconds per batch of the GPU batch builder (data set resident in HBM), the read-back of the pair
+    count included: what a training loop pays per batch on this path instead of the host collate."""
+    from ps_vae_amd.device_data import DeviceMolDataset
+    ds = DeviceMolDataset(mols, tok, dev)
+    rng = random.Random(0)
+    picks = [rng.sample(range(len(ds)), batch_size) for _ in range(iters + 2)]
+    for p in picks[:2]:
+        ds.collate(p)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k, p in enumerate(picks[2:]):
+        ds.collate(p, epoch=k)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
 
 
 def bulk_message_passing(dev, graphs=4096, H=300, iters=40):
@@ -316,6 +334,7 @@ def main():
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
+    dev_collate_ms = device_collate_ms(host_times['mols'], tok, dev, args.batch_size) if world == 1 and not args.no_bulk else None
     comm = 'RCCL' if args.backend == 'nccl' else args.backend
     value = world * args.batch_size * args.steps / elapsed
     table = {}
@@ -355,6 +374,7 @@ def main():
                    'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3,
                    'host_stage2_plus_3_ms_per_batch': host_times.get('per_item_ms'),
                    'host_packed_dataset_ms_per_batch': host_times.get('packed_ms'),
+                   'device_collate_ms_per_batch': dev_collate_ms,
                    'host_enqueue_ms_per_step': host_enqueue_s / args.steps * 1e3},
         'roofline': roofline,
         'message_passing': {'kernels': mp, 'bound': 'hbm', 'achieved': (mp_bytes / (mp_ms * 1e-3) / 1e9) if mp_ms else None,

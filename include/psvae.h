@@ -328,6 +328,50 @@ int psvae_pack_batch(int B, int N, int L, const int32_t* n_atoms,
                      int32_t* blob, int64_t blob_cap, int64_t* offsets, int64_t* blob_words,
                      int32_t* n_nodes_out, int32_t* n_target_tokens_out);
 
+
+/* ---- batches built on the GPU ---------------------------------------------------
+ * Stages 2 and 3 of the reference's dataset (process_step2 / process_step3,
+ * src/data/bpe_dataset.py:56-155) for a data set that lies flattened in DEVICE memory: the result is the same
+ * index blob psvae_pack_batch writes (same fields, same order inside every list), built by kernels on `stream`.
+ * The store holds what is static per molecule m (all int32, local atom numbers 0..n_m-1):
+ *   atoms  atom_off[m]..atom_off[m+1] of atom_id / piece_of_atom / pos_of_atom / group_of_atom (what
+ *          process_step2 leaves in x / x_pieces / x_pos; group = index into the record's `groups`, -1 for none);
+ *   bonds  as a CSR: row bounds rowptr_loc[atom_off[m] + m + a] (n_m + 1 of them), entries
+ *          edge_off[m]..edge_off[m+1] of nbr (neighbour, ascending inside a row) / nbr_type.  A molecule's
+ *          adjacency matrix is symmetric (bpe_dataset.py:62-66), so this one CSR is both the by-target and the
+ *          by-source CSR of the batch; in_* is the same for the bonds inside a piece (edge_select == 0);
+ *   pieces piece_off[m]..piece_off[m+1] of `pieces` (with the leading and trailing <s>);
+ *   props  [n_mols, n_props_all].
+ * Negative pairs (bpe_dataset.py:129: every ordered cross-piece pair without a bond is kept with probability
+ * 0.022) are drawn from a counter-based generator keyed by (seed, epoch, molecule index, pair), NOT from the
+ * reference's MT19937 stream: a molecule's pairs then depend neither on the batch it lands in nor on the number
+ * of GPUs.  neg_rate >= 1 keeps every cross-piece pair; the host path psvae_collate_pairs stays the bit-exact one.
+ * The caller supplies the sizes that follow from the store (n atoms, E directed bonds, E_in in-piece bonds,
+ * L longest piece sequence: sums / maximum over mol_idx) and S_cap, an upper bound of the selected pairs that
+ * fixes the blob layout (sum of n_m^2 always suffices); psvae_collate_device_layout gives the field offsets
+ * (words) and the blob size for them.  counts_out (device, 8 words) receives S, the number of non-pad target
+ * tokens, n, E, E_in, L as the kernels found them, and in word 6 a bit set of inconsistencies (0 = none);
+ * read S from it before calling the step.  Molecules of more than 128 atoms are not supported here. */
+typedef struct psvae_mol_store {
+    int64_t n_mols;
+    const int32_t *atom_off, *atom_id, *piece_of_atom, *pos_of_atom, *group_of_atom;
+    const int32_t *edge_off, *rowptr_loc, *nbr, *nbr_type;
+    const int32_t *in_edge_off, *in_rowptr_loc, *in_nbr, *in_nbr_type;
+    const int32_t *piece_off, *pieces;
+    const float *props;
+    int32_t n_props_all;
+} psvae_mol_store;
+int64_t psvae_collate_device_layout(int B, int n, int64_t E, int64_t E_in, int64_t S_cap, int L, int num_atom,
+                                    int num_piece, int max_pos, int64_t* offsets /* [PSVAE_BLOB_FIELDS] */);
+size_t psvae_collate_device_scratch_bytes(int B, int n, int L, int num_atom, int num_piece, int max_pos);
+int psvae_collate_device(const psvae_mol_store* store, const int32_t* mol_idx /* device [B] */, int B, int n, int64_t E,
+                         int64_t E_in, int L, int64_t S_cap, double neg_rate, uint64_t seed, uint64_t epoch,
+                         int num_atom, int num_piece, int max_pos, int pad_idx,
+                         const int32_t* prop_cols /* host */, int n_prop_cols,
+                         int32_t* blob, int64_t blob_words, float* props_out /* [B, n_prop_cols] */,
+                         float* denoms_out /* [4] */, int32_t* counts_out /* [8] */, void* scratch, size_t scratch_bytes,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

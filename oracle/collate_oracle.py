@@ -92,3 +92,36 @@ def collate(mols2, piece_pad, rng=random):
         'in_piece_edge_idx': in_piece,
         'props': torch.tensor([m['props'] for m in mols2]),
     }
+
+
+# ---- the device collate's negative-pair sampler (ps_vae_amd/csrc/collate_device.hip) ------------------------
+# Not part of the reference: the GPU batch builder replaces `random() < 0.022` (bpe_dataset.py:129) by a
+# counter-based draw per (seed, epoch, molecule, ordered pair).  Restated here so that tests can predict
+# exactly which pairs the kernels select.
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def device_pair_uniform(seed, epoch, mol, pair):
+    """Uniform in [0, 1) the device collate draws for ordered pair `pair` = m * n_atoms + k of molecule `mol`."""
+    key0 = _mix64(_mix64(seed & _M64) ^ (epoch & _M64))
+    key_mol = _mix64(key0 ^ (mol & 0xFFFFFFFF))
+    return (_mix64(key_mol ^ pair) >> 11) * (1.0 / 9007199254740992.0)
+
+
+def device_select_pairs(ad, cross, seed, epoch, mol, rate):
+    """Ordered pairs (m, k, bond type) of one molecule in row-major order, as the device collate keeps them:
+    cross-piece pairs that are bonded or whose draw is below `rate` (the rule of bpe_dataset.py:125-132)."""
+    n = len(ad)
+    out = []
+    for m in range(n):
+        for k in range(n):
+            if cross[m][k] and (ad[m][k] != 0 or device_pair_uniform(seed, epoch, mol, m * n + k) < rate):
+                out.append((m, k, int(ad[m][k])))
+    return out

@@ -13,9 +13,12 @@ def __getattr__(name):
     if name in ('Encoder', 'VAEPieceDecoder', 'Predictor', 'MLP'):
         from . import modules
         return getattr(modules, name)
-    if name in ('BPEMolDataset', 'get_dataloader', 'to_device', 'NativeBatch'):
+    if name in ('BPEMolDataset', 'PackedMolDataset', 'get_dataloader', 'to_device', 'NativeBatch'):
         from . import data
         return getattr(data, name)
+    if name == 'DeviceMolDataset':
+        from .device_data import DeviceMolDataset
+        return DeviceMolDataset
     if name == 'FusedClipAdam':
         from .optim import FusedClipAdam
         return FusedClipAdam

@@ -77,6 +77,12 @@ class Batch(C.Structure):
                 [('props', vp), ('eps', vp), ('denoms', vp), ('conds', vp), ('d_conds', vp), ('d_z', vp)])
 
 
+class MolStore(C.Structure):
+    _fields_ = ([('n_mols', i64)] + [(k, vp) for k in (
+        'atom_off', 'atom_id', 'piece_of_atom', 'pos_of_atom', 'group_of_atom', 'edge_off', 'rowptr_loc', 'nbr', 'nbr_type',
+        'in_edge_off', 'in_rowptr_loc', 'in_nbr', 'in_nbr_type', 'piece_off', 'pieces', 'props')] + [('n_props_all', i32)])
+
+
 _lib = None
 
 
@@ -134,6 +140,13 @@ def lib():
     L.psvae_pack_bound.argtypes = [C.c_int, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.psvae_pack_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp,
                                    i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, P(i64), P(i32), P(i32)]
+    L.psvae_collate_device_layout.restype = i64
+    L.psvae_collate_device_layout.argtypes = [C.c_int, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_collate_device_scratch_bytes.restype = sz
+    L.psvae_collate_device_scratch_bytes.argtypes = [C.c_int] * 6
+    L.psvae_collate_device.argtypes = [P(MolStore), vp, C.c_int, C.c_int, i64, i64, C.c_int, i64, C.c_double, C.c_uint64,
+                                       C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, vp, vp,
+                                       vp, sz, vp]
     L.psvae_profile_enable.argtypes = [C.c_int]
     L.psvae_profile_num_classes.restype = C.c_int
     L.psvae_profile_class_name.restype = C.c_char_p
@@ -155,7 +168,8 @@ EXPORTS = (
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',
     'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs', 'psvae_gather_molecules',
-    'psvae_pack_bound', 'psvae_pack_batch', 'psvae_profile_enable', 'psvae_profile_num_classes',
+    'psvae_pack_bound', 'psvae_pack_batch', 'psvae_collate_device_layout', 'psvae_collate_device_scratch_bytes',
+    'psvae_collate_device', 'psvae_profile_enable', 'psvae_profile_num_classes',
     'psvae_profile_class_name', 'psvae_profile_collect', 'psvae_profile_event_overhead_ms')
 
 

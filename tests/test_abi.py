@@ -45,6 +45,7 @@ def test_ctypes_structs_mirror_the_header():
     assert len(_lib.Dims._fields_) == struct_fields('psvae_dims')
     assert len(_lib.Params._fields_) == struct_fields('psvae_params')
     assert len(_lib.Batch._fields_) == struct_fields('psvae_batch')
+    assert len(_lib.MolStore._fields_) == struct_fields('psvae_mol_store')
     assert C.sizeof(_lib.Params) == 8 * len(_lib.Params._fields_)
     assert len(_lib.BLOB_FIELDS) == len(re.findall(r'PSVAE_BLOB_[A-Z_]+', HEADER.split('enum {')[-1].split('}')[0])) - 1
 
@@ -69,3 +70,22 @@ def test_no_cpu_path():
     assert len(model.state_dict()) == 51
     with pytest.raises(RuntimeError, match='GPU'):
         model({'x': torch.zeros(1, 1, dtype=torch.long)})
+
+
+def test_device_collate_layout_is_the_host_builders_layout():
+    """The blob layout the GPU batch builder is told to fill (a host-side function) equals the layout
+    psvae_pack_batch produces for the same counts."""
+    import random
+    from ps_vae_amd import Tokenizer, synth
+    from ps_vae_amd.data import BPEMolDataset, PackedMolDataset
+    tok = Tokenizer.synthetic(300)
+    random.seed(3)
+    nb = PackedMolDataset(synth.make_molecules(9, 'zinc', 300, 24), tok).collate_fn(list(range(24)))['_native']
+    sz = nb.sizes
+    off = (C.c_int64 * len(_lib.BLOB_FIELDS))()
+    words = _lib.lib().psvae_collate_device_layout(sz['B'], sz['n'], sz['E'], sz['E_in'], sz['S'], sz['L'], tok.num_atom_type(),
+                                                   tok.num_piece_type(), BPEMolDataset.max_pos, off)
+    assert list(off) == list(nb.offsets) and words == nb.blob.numel()
+    assert _lib.lib().psvae_collate_device_layout(0, 1, 0, 0, 0, 2, 11, 302, 50, off) == -1
+    assert _lib.lib().psvae_collate_device(None, None, 1, 1, 0, 0, 2, 1, 0.0, 0, 0, 11, 302, 50, 300, None, 1, None, 0, None,
+                                          None, None, None, 0, None) == -1          # PSVAE_E_NULL before any launch
