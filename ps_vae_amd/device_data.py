@@ -109,3 +109,45 @@ class DeviceMolDataset:
             raise RuntimeError(f'psvae_collate_device: inconsistent sizes or keys (flags {got[6]:#x})')
         sizes = dict(B=B, n=n, E=E, E_in=E_in, S=got[0], L=L)
         return {'_native': NativeBatch(blob, [int(o) for o in offsets], sizes, props, denoms)}
+
+
+class DeviceLoader:
+    """Iterates over a `DeviceMolDataset` in batches, as `get_dataloader(...)` iterates over the host data sets
+    (`src/data/bpe_dataset.py:184-187`): `shuffle` draws a new order every epoch (`set_epoch`, which also keys
+    the negative-pair draws).  The next batch is built on a side stream while the caller's stream still runs
+    the step of the previous one; the only host wait per batch is the read-back of the next batch's pair count."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, seed=0, all_pairs=False, drop_last=False):
+        self.dataset, self.batch_size, self.shuffle, self.seed = dataset, int(batch_size), shuffle, int(seed)
+        self.all_pairs, self.drop_last, self.epoch = all_pairs, drop_last, 0
+        self._side = torch.cuda.Stream(device=dataset.device)
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def batches(self):
+        order = np.arange(len(self.dataset))
+        if self.shuffle:
+            order = np.random.default_rng([self.seed, self.epoch]).permutation(order)
+        return [order[k * self.batch_size:(k + 1) * self.batch_size] for k in range(len(self))]
+
+    def __iter__(self):
+        main = torch.cuda.current_stream(self.dataset.device)
+        pending = None
+        self._side.wait_stream(main)            # the data set was uploaded on the caller's stream
+        for idx in self.batches():
+            with torch.cuda.stream(self._side):
+                batch = self.dataset.collate(idx, epoch=self.epoch, all_pairs=self.all_pairs)
+            nb = batch['_native']
+            for t in (nb.blob, nb.props, nb.denoms):
+                t.record_stream(main)           # built on the side stream, consumed on the caller's
+            if pending is not None:
+                yield pending
+            pending = batch
+            main.wait_stream(self._side)
+        if pending is not None:
+            yield pending

@@ -7,7 +7,7 @@ import torch
 
 from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config, synth
 from ps_vae_amd.data import BPEMolDataset, PackedMolDataset, pack_native
-from ps_vae_amd.device_data import DeviceMolDataset
+from ps_vae_amd.device_data import DeviceLoader, DeviceMolDataset
 from oracle import collate_oracle as CO
 
 pytestmark = pytest.mark.gpu
@@ -136,3 +136,32 @@ def test_training_step_on_a_device_built_batch():
         outs.append((torch.stack([pred, rec, piece, edge, kl]).detach().clone(), model.flat_buffers()[1].clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[0][0]).all()
+
+
+def test_loader_feeds_the_epoch_loop():
+    """`fit` over a `DeviceLoader`: the batches it yields are the ones `collate` builds for the same indices and
+    epoch, every molecule is seen once per epoch, and the loss goes down."""
+    from ps_vae_amd.trainer import fit
+    tok = Tokenizer.synthetic(V)
+    mols = synth.make_molecules(8, 'qm9', V, 96)
+    ds = DeviceMolDataset(mols, tok, 'cuda:0', seed=4)
+    train = DeviceLoader(ds, 16, shuffle=True, seed=1)
+    valid = DeviceLoader(DeviceMolDataset(mols[:32], tok, 'cuda:0', seed=4), 16)
+    train.set_epoch(3)
+    seen = []
+    for idx, batch in zip(train.batches(), train):
+        want = ds.collate(idx, epoch=3)['_native']
+        got = batch['_native']
+        assert got.sizes == want.sizes and torch.equal(got.blob, want.blob) and torch.equal(got.denoms, want.denoms)
+        seen += list(idx)
+    assert sorted(seen) == list(range(96)) and seen != list(range(96))
+    torch.manual_seed(0)
+    model = PSVAEModel(full_config(default_args(), tok), tok).cuda()
+
+    class Epochs:       # what a training script does between epochs
+        def __iter__(self):
+            train.set_epoch(train.epoch + 1)
+            return iter(train)
+    history = fit(model, Epochs(), valid, max_epochs=4)
+    assert len(history) == 4 and all(np.isfinite(h['val_loss']) for h in history)
+    assert history[-1]['val_loss'] < history[0]['val_loss']
