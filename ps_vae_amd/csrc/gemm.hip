@@ -129,14 +129,31 @@ __device__ __forceinline__ void store_stage(float (*s)[Pitch<T>::value], const S
     }
 }
 
+// One K-step of a wave: 16 MFMAs over the [k][row] images.  The operand reads run one group of four MFMAs
+// ahead of the matrix pipe (two named register groups), so that the LDS latency of a group is covered by the
+// 256 cycles the previous group's MFMAs take instead of being paid between them.
 template <int LA, int LB>
 __device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LA], const float (*sb)[LB], int arow, int brow,
                                               int kh, floatx16 acc) {
+    float a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-        const float a = sa[kk * 2 + kh][arow];
-        const float b = sb[kk * 2 + kh][brow];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) { a0[u] = sa[u * 2 + kh][arow]; b0[u] = sb[u * 2 + kh][brow]; }
+#pragma unroll
+    for (int g = 0; g < BK / 8; g += 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a1[u] = sa[(g + 1) * 8 + u * 2 + kh][arow]; b1[u] = sb[(g + 1) * 8 + u * 2 + kh][brow]; }
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler would otherwise sink every read to just before its MFMA)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < BK / 8) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0[u] = sa[(g + 2) * 8 + u * 2 + kh][arow]; b0[u] = sb[(g + 2) * 8 + u * 2 + kh][brow]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }
@@ -162,35 +179,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     if (nk > 0) {
         const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = lane >> 5;
         const TileGeo ga{A, p.lda, m0, p.M, rend, -1}, gb{B, p.ldb, n0, p.N, rend, p.ones_col};
-        // two register stages, named so that every access is static: stage (kt & 1) carries tile kt
-        Stage a0 = load_stage<AT, VEC>(ga, rbeg, tid);
-        Stage b0 = load_stage<BT, VEC>(gb, rbeg, tid);
-        Stage a1 = load_stage<AT, VEC>(ga, rbeg + BK, tid);   // all zeros once stored when nk == 1
-        Stage b1 = load_stage<BT, VEC>(gb, rbeg + BK, tid);
-        store_stage<AT>(sA[0], a0, ga, rbeg, tid);
-        store_stage<BT>(sB[0], b0, gb, rbeg, tid);
+        // Four register stages, named so that every access is static.  Invariant at the top of a quad of K-steps
+        // (kt a multiple of 4): LDS buffer 0 holds tile kt, stages 0/1/2 hold tiles kt+1/kt+2/kt+3 (loaded or in
+        // flight), stage 3 is free.  Every K-step fetches the tile four steps ahead into the stage that has just
+        // been freed, so a load has three K-steps of MFMA work (~1.3 us) to arrive before it is written to LDS:
+        // with one or two workgroups on a CU nothing else hides the latency of these loads.  Loads and LDS
+        // stores are unconditional (a branch around a load makes the compiler wait at the join for the loads it
+        // has just issued): tiles past the end of the reduction range are fetched from a clamped address and,
+        // if they are stored at all, stored as zeros.  The loop runs whole quads; the 0-3 K-steps left over
+        // only consume stages that are already on their way, so their uniform branches contain no loads.
+        Stage a3 = load_stage<AT, VEC>(ga, rbeg, tid);
+        Stage b3 = load_stage<BT, VEC>(gb, rbeg, tid);
+        Stage a0 = load_stage<AT, VEC>(ga, rbeg + BK, tid);
+        Stage b0 = load_stage<BT, VEC>(gb, rbeg + BK, tid);
+        Stage a1 = load_stage<AT, VEC>(ga, rbeg + 2 * BK, tid);
+        Stage b1 = load_stage<BT, VEC>(gb, rbeg + 2 * BK, tid);
+        Stage a2 = load_stage<AT, VEC>(ga, rbeg + 3 * BK, tid);
+        Stage b2 = load_stage<BT, VEC>(gb, rbeg + 3 * BK, tid);
+        store_stage<AT>(sA[0], a3, ga, rbeg, tid);
+        store_stage<BT>(sB[0], b3, gb, rbeg, tid);
         __syncthreads();
-        // Invariant at the top of an iteration: LDS buffer 0 holds tile kt, stage 1 holds tile kt+1 (in flight).
-        // Loads and LDS stores are unconditional: tiles past the end of the reduction range are fetched from a
-        // clamped address and stored as zeros (a branch around a load makes the compiler wait at the join for
-        // the loads it has just issued).  The loop always runs whole pairs of K-steps; a pair's second tile may
-        // be such an all-zero tile.
-        for (int kt = 0; kt < nk; kt += 2) {
-            const int r1 = rbeg + (kt + 1) * BK, r2 = r1 + BK, r3 = r2 + BK;
-            // even half: compute tile kt from buffer 0; stage 0 is free -> fetch tile kt+2 into it
-            a0 = load_stage<AT, VEC>(ga, r2, tid);
-            b0 = load_stage<BT, VEC>(gb, r2, tid);
+        const int nq = nk >> 2, rem = nk & 3;
+        for (int q = 0; q < nq; ++q) {
+            const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
+            a3 = load_stage<AT, VEC>(ga, r4, tid);
+            b3 = load_stage<BT, VEC>(gb, r4, tid);
             acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
-            store_stage<AT>(sA[1], a1, ga, r1, tid);
-            store_stage<BT>(sB[1], b1, gb, r1, tid);
+            store_stage<AT>(sA[1], a0, ga, r1, tid);
+            store_stage<BT>(sB[1], b0, gb, r1, tid);
             __syncthreads();
-            // odd half: compute tile kt+1 from buffer 1; stage 1 is free -> fetch tile kt+3
-            a1 = load_stage<AT, VEC>(ga, r3, tid);
-            b1 = load_stage<BT, VEC>(gb, r3, tid);
+            a0 = load_stage<AT, VEC>(ga, r4 + BK, tid);
+            b0 = load_stage<BT, VEC>(gb, r4 + BK, tid);
             acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
-            store_stage<AT>(sA[0], a0, ga, r2, tid);
-            store_stage<BT>(sB[0], b0, gb, r2, tid);
+            store_stage<AT>(sA[0], a1, ga, r2, tid);
+            store_stage<BT>(sB[0], b1, gb, r2, tid);
             __syncthreads();
+            a1 = load_stage<AT, VEC>(ga, r4 + 2 * BK, tid);
+            b1 = load_stage<BT, VEC>(gb, r4 + 2 * BK, tid);
+            acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
+            store_stage<AT>(sA[1], a2, ga, r3, tid);
+            store_stage<BT>(sB[1], b2, gb, r3, tid);
+            __syncthreads();
+            a2 = load_stage<AT, VEC>(ga, r4 + 3 * BK, tid);
+            b2 = load_stage<BT, VEC>(gb, r4 + 3 * BK, tid);
+            acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
+            store_stage<AT>(sA[0], a3, ga, r4, tid);
+            store_stage<BT>(sB[0], b3, gb, r4, tid);
+            __syncthreads();
+        }
+        // buffer 0 holds tile 4 nq; stages 0 and 1 hold the next two
+        const int rt = rbeg + 4 * nq * BK;
+        if (rem >= 1) acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
+        if (rem >= 2) {
+            store_stage<AT>(sA[1], a0, ga, rt + BK, tid);
+            store_stage<BT>(sB[1], b0, gb, rt + BK, tid);
+            __syncthreads();
+            acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
+        }
+        if (rem >= 3) {
+            store_stage<AT>(sA[0], a1, ga, rt + 2 * BK, tid);
+            store_stage<BT>(sB[0], b1, gb, rt + 2 * BK, tid);
+            __syncthreads();
+            acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
         }
     }
 
