@@ -114,13 +114,16 @@ __device__ __forceinline__ void store_quad(float (*s)[Pitch<T>::value], float4 v
         *reinterpret_cast<float4*>(&s[q >> 4][(q & 15) << 2]) = v;
     }
 }
-// Write a loaded stage into its LDS image.  A tile that lies wholly inside the matrix (the common case,
-// decided per workgroup and K-step, so the branch is uniform) is written as loaded; any other tile has
-// its out-of-range elements zeroed and the ones column filled in.
+// Write a loaded stage into its LDS image.  Only the REDUCTION range needs care: an element past its end would
+// add to every output, so a tile that overhangs it has those elements zeroed.  A tile that overhangs the
+// OUTPUT range is written as loaded: row o of an operand only ever meets output row (column) o, rows past the
+// matrix produce outputs the epilogue never writes, and their loads come from clamped, valid addresses.  The
+// one output index with a value of its own is the ones column (bias-gradient trick), filled in by the flagged
+// path too.  The branch is uniform per workgroup and K-step.
 template <bool T>
 __device__ __forceinline__ void store_stage(float (*s)[Pitch<T>::value], const Stage& st, const TileGeo& g, int r0, int tid) {
-    const int olim = T ? (g.ones_col >= 0 ? g.ones_col : g.o_lim) : g.o_lim;
-    if (g.o0 + BM <= olim && r0 + BK <= g.r_lim) {
+    const bool ones_here = T && g.ones_col >= g.o0 && g.ones_col < g.o0 + BM;
+    if (r0 + BK <= g.r_lim && !ones_here) {
         store_quad<T>(s, st.v0, tid);
         store_quad<T>(s, st.v1, tid + 256);
     } else {
