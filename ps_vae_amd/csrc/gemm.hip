@@ -161,7 +161,79 @@ __device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LA], const float
     return acc;
 }
 
-template <bool AT, bool BT, bool VEC>
+template <bool T, bool EDGE>
+__device__ __forceinline__ void store_half(float (*s)[Pitch<T>::value], float4 v, const TileGeo& g, int r0, int q) {
+    store_quad<T>(s, EDGE ? apply_flags(v, quad_flags<T>(g, r0, q)) : v, q);
+}
+
+// One K-step of the main loop as ONE instruction stream per wave.  With a few thousand rows there is at most one
+// wave per SIMD, so nothing but the wave's own instruction order can keep the matrix pipe busy: a wave issues in
+// order and every MFMA waits for the previous one (same accumulator), which leaves ~60 idle issue cycles after
+// each of the 16 MFMAs.  Everything else the K-step has to do is dealt into those gaps - the global loads of the
+// tile four steps ahead, the LDS reads of the next group of four MFMAs, the LDS writes of the next tile (other
+// buffer) - instead of running before and after the MFMA chain.  The scheduling barriers pin that order.
+// EDGE: the tile being stored overhangs the reduction range or holds the ones column (see store_stage).
+#define PSVAE_SB() __builtin_amdgcn_sched_barrier(0)
+#define PSVAE_MFMA(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+template <bool AT, bool BT, bool VEC, bool EDGE>
+__device__ __forceinline__ void kstep(const float (*cA)[Pitch<AT>::value], const float (*cB)[Pitch<BT>::value],
+                                      float (*nA)[Pitch<AT>::value], float (*nB)[Pitch<BT>::value],
+                                      const TileGeo& ga, const TileGeo& gb, Stage& la, Stage& lb, int r_load,
+                                      const Stage& sa, const Stage& sb, int r_store, int arow, int brow, int kh, int tid,
+                                      floatx16& acc) {
+    float a0[4], b0[4], a1[4], b1[4];
+#define PSVAE_READ(A_, B_, G_)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+        A_[u] = cA[(G_) * 8 + u * 2 + kh][arow]; B_[u] = cB[(G_) * 8 + u * 2 + kh][brow];           \
+    }
+    PSVAE_READ(a0, b0, 0)
+    PSVAE_SB();
+    PSVAE_MFMA(a0[0], b0[0]);
+    la = load_stage<AT, VEC>(ga, r_load, tid);
+    PSVAE_SB();
+    PSVAE_MFMA(a0[1], b0[1]);
+    lb = load_stage<BT, VEC>(gb, r_load, tid);
+    PSVAE_SB();
+    PSVAE_MFMA(a0[2], b0[2]);
+    PSVAE_READ(a1, b1, 1)
+    PSVAE_SB();
+    PSVAE_MFMA(a0[3], b0[3]);
+    store_half<AT, EDGE>(nA, sa.v0, ga, r_store, tid);
+    PSVAE_SB();
+    PSVAE_MFMA(a1[0], b1[0]);
+    PSVAE_SB();
+    PSVAE_MFMA(a1[1], b1[1]);
+    store_half<AT, EDGE>(nA, sa.v1, ga, r_store, tid + 256);
+    PSVAE_SB();
+    PSVAE_MFMA(a1[2], b1[2]);
+    PSVAE_READ(a0, b0, 2)
+    PSVAE_SB();
+    PSVAE_MFMA(a1[3], b1[3]);
+    PSVAE_SB();
+    PSVAE_MFMA(a0[0], b0[0]);
+    store_half<BT, EDGE>(nB, sb.v0, gb, r_store, tid);
+    PSVAE_SB();
+    PSVAE_MFMA(a0[1], b0[1]);
+    PSVAE_SB();
+    PSVAE_MFMA(a0[2], b0[2]);
+    PSVAE_READ(a1, b1, 3)
+    PSVAE_SB();
+    PSVAE_MFMA(a0[3], b0[3]);
+    store_half<BT, EDGE>(nB, sb.v1, gb, r_store, tid + 256);
+    PSVAE_SB();
+    PSVAE_MFMA(a1[0], b1[0]);
+    PSVAE_MFMA(a1[1], b1[1]);
+    PSVAE_MFMA(a1[2], b1[2]);
+    PSVAE_MFMA(a1[3], b1[3]);
+    PSVAE_SB();
+    __syncthreads();
+#undef PSVAE_READ
+}
+
+// PIPE selects the main loop: the hand-interleaved K-step (one instruction stream that keeps the matrix pipe fed
+// from a single wave per SIMD; ~200 VGPRs, two waves per SIMD at most) for launches of a few workgroups per CU,
+// the plain loop (~140 VGPRs, relies on several co-resident workgroups to overlap its phases) for large ones.
+template <bool AT, bool BT, bool VEC, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) float sA[2][BK][Pitch<AT>::value];
     __shared__ __attribute__((aligned(16))) float sB[2][BK][Pitch<BT>::value];
@@ -203,32 +275,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
         store_stage<BT>(sB[0], b3, gb, rbeg, tid);
         __syncthreads();
         const int nq = nk >> 2, rem = nk & 3;
-        for (int q = 0; q < nq; ++q) {
-            const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
-            a3 = load_stage<AT, VEC>(ga, r4, tid);
-            b3 = load_stage<BT, VEC>(gb, r4, tid);
-            acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
-            store_stage<AT>(sA[1], a0, ga, r1, tid);
-            store_stage<BT>(sB[1], b0, gb, r1, tid);
-            __syncthreads();
-            a0 = load_stage<AT, VEC>(ga, r4 + BK, tid);
-            b0 = load_stage<BT, VEC>(gb, r4 + BK, tid);
-            acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
-            store_stage<AT>(sA[0], a1, ga, r2, tid);
-            store_stage<BT>(sB[0], b1, gb, r2, tid);
-            __syncthreads();
-            a1 = load_stage<AT, VEC>(ga, r4 + 2 * BK, tid);
-            b1 = load_stage<BT, VEC>(gb, r4 + 2 * BK, tid);
-            acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
-            store_stage<AT>(sA[1], a2, ga, r3, tid);
-            store_stage<BT>(sB[1], b2, gb, r3, tid);
-            __syncthreads();
-            a2 = load_stage<AT, VEC>(ga, r4 + 3 * BK, tid);
-            b2 = load_stage<BT, VEC>(gb, r4 + 3 * BK, tid);
-            acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
-            store_stage<AT>(sA[0], a3, ga, r4, tid);
-            store_stage<BT>(sB[0], b3, gb, r4, tid);
-            __syncthreads();
+        if constexpr (PIPE) {
+            const bool ones_tile = BT && p.ones_col >= n0 && p.ones_col < n0 + BN;     // uniform
+            for (int q = 0; q < nq; ++q) {
+                const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
+                if (!ones_tile && r4 + BK <= rend) {
+                    kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, a2, b2, r4 + 3 * BK, a3, b3, r4, arow, brow, kh, tid, acc);
+                } else {
+                    kstep<AT, BT, VEC, true>(sA[0], sB[0], sA[1], sB[1], ga, gb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[1], sB[1], sA[0], sB[0], ga, gb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[0], sB[0], sA[1], sB[1], ga, gb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[1], sB[1], sA[0], sB[0], ga, gb, a2, b2, r4 + 3 * BK, a3, b3, r4, arow, brow, kh, tid, acc);
+                }
+            }
+        } else {
+            for (int q = 0; q < nq; ++q) {
+                const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
+                a3 = load_stage<AT, VEC>(ga, r4, tid);
+                b3 = load_stage<BT, VEC>(gb, r4, tid);
+                acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
+                store_stage<AT>(sA[1], a0, ga, r1, tid);
+                store_stage<BT>(sB[1], b0, gb, r1, tid);
+                __syncthreads();
+                a0 = load_stage<AT, VEC>(ga, r4 + BK, tid);
+                b0 = load_stage<BT, VEC>(gb, r4 + BK, tid);
+                acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
+                store_stage<AT>(sA[0], a1, ga, r2, tid);
+                store_stage<BT>(sB[0], b1, gb, r2, tid);
+                __syncthreads();
+                a1 = load_stage<AT, VEC>(ga, r4 + 2 * BK, tid);
+                b1 = load_stage<BT, VEC>(gb, r4 + 2 * BK, tid);
+                acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
+                store_stage<AT>(sA[1], a2, ga, r3, tid);
+                store_stage<BT>(sB[1], b2, gb, r3, tid);
+                __syncthreads();
+                a2 = load_stage<AT, VEC>(ga, r4 + 3 * BK, tid);
+                b2 = load_stage<BT, VEC>(gb, r4 + 3 * BK, tid);
+                acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
+                store_stage<AT>(sA[0], a3, ga, r4, tid);
+                store_stage<BT>(sB[0], b3, gb, r4, tid);
+                __syncthreads();
+            }
         }
         // buffer 0 holds tile 4 nq; stages 0 and 1 hold the next two
         const int rt = rbeg + 4 * nq * BK;
@@ -396,9 +486,13 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
         const bool vec = p.a_vec && p.b_vec;
 #define PSVAE_GEMM_LAUNCH(AT_, BT_)                                                                          \
         do {                                                                                                  \
-            if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, true>), grid, dim3(256), 0, s, p);         \
-            else hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, false>), grid, dim3(256), 0, s, p);            \
+            if (vec && pipe) hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, true, true>), grid, dim3(256), 0, s, p);   \
+            else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, true, false>), grid, dim3(256), 0, s, p);   \
+            else hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, false, false>), grid, dim3(256), 0, s, p);           \
         } while (0)
+        // the interleaved loop pays where a CU holds few workgroups and the operands are not both transposed
+        // (the weight-gradient products run long reductions over many co-resident workgroups)
+        const bool pipe = !(d.a_t && d.b_t) && (long long)grid.x * grid.y * grid.z <= 1024;
         if (!d.a_t && !d.b_t) PSVAE_GEMM_LAUNCH(false, false);
         else if (!d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(false, true);
         else if (d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(true, true);
