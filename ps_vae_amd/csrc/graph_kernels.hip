@@ -43,7 +43,9 @@ __device__ __forceinline__ void stage_edge_tab(float* tab, const float* __restri
 }
 
 struct AggArgs { AggGroup g[2]; int ldx, ldo, n, H4; };
-constexpr int AGG_FWD_MAX_BLOCKS = 768;   // per group: 3 blocks per CU; larger inputs loop (more blocks in flight measured slower)
+// Blocks per group: one item per thread up to 4 blocks per CU; beyond that the blocks loop, and 3 per CU
+// streamed fastest from HBM (more blocks in flight measured slower).
+constexpr int AGG_FWD_MAX_BLOCKS = 1024, AGG_FWD_LOOP_BLOCKS = 768;
 
 // Forward aggregation, software-pipelined over a thread's items (node, channel chunk).  An item needs three
 // dependent memory round trips: its CSR row bounds, then the neighbour indices and bond types of its first
@@ -533,7 +535,7 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     // ... and addresses rows by 32-bit byte offsets built with 24-bit multiplies
     if (n >= (1 << 24) || ldx >= (1 << 22) || ldo >= (1 << 22) || (long long)n * ldx >= (1LL << 30) || (long long)n * ldo >= (1LL << 30)) return PSVAE_E_SHAPE;
     const long long blocks = (items + 255) / 256;
-    dim3 grid((unsigned)(blocks < AGG_FWD_MAX_BLOCKS ? blocks : AGG_FWD_MAX_BLOCKS), ngroups);
+    dim3 grid((unsigned)(blocks <= AGG_FWD_MAX_BLOCKS ? blocks : AGG_FWD_LOOP_BLOCKS), ngroups);
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += 2.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1);
     ProfScope prof(s, KC_AGG_FWD, bytes);

@@ -45,7 +45,7 @@ def main():
         out[cls] = {'launches_sampled': nf[cls], 'FETCH_SIZE_KiB_per_launch': f, 'WRITE_SIZE_KiB_per_launch': w,
                     'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0}
     json.dump({'formula': 'hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 read-side correction)',
-               'command': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0',
+               'command': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bulk --profile-steps 1',
                'workload': 'zinc, vocab 300, batch 128', 'classes': out}, open(sys.argv[3], 'w'), indent=1)
     for k, v in out.items():
         print(f"{k:20s} {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB/launch  ({v['launches_sampled']} launches)")
