@@ -567,6 +567,9 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
     {   // the kernel addresses rows by 32-bit byte offsets built with 24-bit multiplies
         const int ldmax = ldda > ldx ? (ldda > lddx ? ldda : lddx) : (ldx > lddx ? ldx : lddx);
         if (n >= (1 << 24) || ldmax >= (1 << 22) || ldp >= (1 << 22) || (long long)n * ldmax >= (1LL << 30)) return PSVAE_E_SHAPE;
+        // the pooled gradient is indexed by graph; there are at most n graphs
+        for (int k = 0; k < ngroups; ++k)
+            if (g[k].dpool && (long long)n * ldp >= (1LL << 30)) return PSVAE_E_SHAPE;
     }
     bool need_tab = false;
     for (int k = 0; k < ngroups; ++k) need_tab = need_tab || g[k].da != nullptr;
