@@ -90,8 +90,6 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) float etab_lds[];
     const AggGroup& g = a.g[blockIdx.y];
     const int H = a.H4 * 4;
-    for (int k = threadIdx.x; k < H; k += blockDim.x) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
-    stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
     // 32-bit item arithmetic (the launcher checks n * H/4 < 2^31)
     // All blocks sweep the items together, one window of gridDim.x * 256 items at a time (HBM sees one moving
     // front, as in a plain copy).  Inside a window, workgroups are dealt to the 8 XCDs round-robin by block id,
@@ -101,8 +99,8 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     const unsigned total = (unsigned)a.n * H4;
     const unsigned per_xcd = gridDim.x / 8, bx = blockIdx.x;
     const unsigned logical = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
-    const unsigned tfirst = logical * blockDim.x + threadIdx.x;
-    if (tfirst >= total) return;
+    const unsigned tfirst = min(logical * blockDim.x + threadIdx.x, total - 1);
+    const bool active = logical * blockDim.x + threadIdx.x < total;
     // the edge count is the last row bound; a batch without edges reads its (unused) indices from rowptr[0] = 0
     const int E = g.rowptr[a.n], emax = max(E - 1, 0);
     const int32_t* __restrict__ col = E > 0 ? g.col : g.rowptr;
@@ -116,6 +114,10 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     int iB = (int)(tB / H4), cB = (int)(tB - (unsigned)iB * H4) * 4;
     int eB0 = ldi(g.rowptr, iB), eB1 = ldi(g.rowptr, iB + 1);
     AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
+    // the edge table is staged while those index loads are in flight (a short launch is a chain of latencies)
+    for (int k = threadIdx.x; k < H; k += blockDim.x) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
+    stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
+    if (!active) return;
     for (unsigned t = tfirst; t < total; t += stride) {
         // stage 3 of item A: its own row and four neighbour rows
         const float4 xi = ld4r(x, iA, ldxb, cA);
@@ -190,10 +192,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
             st4(g.dx + (long long)j * a.lddx + c, g.dpool ? ld4(g.dpool + (long long)a.node_graph[j] * a.ldp + c) : zero);
         return;
     }
-    for (int k = tid; k < H; k += 256) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
-    stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
     float4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
-    if (lane_on && node0 + slot < nend) {
+    const bool active = lane_on && node0 + slot < nend;
+    // pipeline fill first (every thread, from clamped node numbers), so that the staging of the edge table below
+    // overlaps the latency of these index loads
+    {
         // the edge count is the last row bound; a batch without edges reads its (unused) indices from rowptr_t[0] = 0
         const int E = g.rowptr_t[a.n], emax = max(E - 1, 0);
         const int32_t* __restrict__ col = E > 0 ? g.col_t : g.rowptr_t;
@@ -204,11 +207,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
         const float* __restrict__ x = g.x;
         const float* __restrict__ da = g.da;
         const unsigned ldxb = (unsigned)a.ldx * 4u, lddab = (unsigned)a.ldda * 4u, lddxb = (unsigned)a.lddx * 4u, ldpb = (unsigned)a.ldp * 4u;
-        int jA = node0 + slot, jB = min(jA + a.nps, nend - 1);
+        int jA = min(node0 + slot, nend - 1), jB = min(jA + a.nps, nend - 1);
         int eA0 = ldi(g.rowptr_t, jA), eA1 = ldi(g.rowptr_t, jA + 1), gA = has_pool ? ldi(ngraph, jA) : 0;
         int eB0 = ldi(g.rowptr_t, jB), eB1 = ldi(g.rowptr_t, jB + 1), gB = has_pool ? ldi(ngraph, jB) : 0;
         AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
-        for (int j = jA; j < nend; j += a.nps) {
+        for (int k = tid; k < H; k += 256) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
+        stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
+        for (int j = active ? jA : nend; j < nend; j += a.nps) {
             // stage 3 of node A: its own rows, the rows of its four first out-neighbours, its graph's pooled gradient
             const float4 xj = ld4r(x, jA, ldxb, c), dj = ld4r(da, jA, lddab, c);
             const float4 d0 = ld4r(da, qA.j0, lddab, c), d1 = ld4r(da, qA.j1, lddab, c);
