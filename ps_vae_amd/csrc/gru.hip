@@ -450,8 +450,16 @@ static bool coop_ok(int R, const void* exch, size_t exch_bytes, int B, int T) {
            exch_bytes >= gru_exchange_bytes(B, T, R);
 }
 
+// Zero the exchange buffer of the multi-CU kernels ahead of time (gru_fwd / gru_bwd then take exch_clean = true
+// and skip their own memset, which otherwise sits on the dependent chain right in front of the recurrence).
+int gru_exchange_clear(hipStream_t s, void* exch, size_t exch_bytes, int B, int T, int R) {
+    if (!exch || B == 0 || T == 0 || !coop_ok(R, exch, exch_bytes, B, T)) return 0;
+    hipError_t e = hipMemsetAsync(exch, 0, gru_exchange_bytes(B, T, R), s);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes) {
+            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean) {
     if (B == 0 || T == 0) return 0;
     if (R % 4 || !aligned16(whh)) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, ntiles = R16 / 16;
@@ -459,8 +467,10 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
         const int n_st = (B + ROWS - 1) / ROWS;
         const size_t used = (size_t)EXCH_HEADER_WORDS * 8 + 2 * (size_t)n_st * R * ROWS * 8;
         ProfScope prof(s, KC_GRU_FWD, 2.0 * B * T * 3 * R * R);
-        hipError_t e = hipMemsetAsync(exch, 0, used, s);
-        if (e != hipSuccess) return (int)e;
+        if (!exch_clean) {
+            hipError_t e = hipMemsetAsync(exch, 0, used, s);
+            if (e != hipSuccess) return (int)e;
+        }
         const dim3 grid(ntiles, coop_slots(ntiles, n_st));
         if ((R >> 2) <= 52)
             hipLaunchKernelGGL(gru_fwd_coop_kernel<13>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
@@ -482,15 +492,17 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
 }
 
 int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
-            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes) {
+            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean) {
     if (B == 0) return 0;
     if (R % 4) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, G16 = (3 * R + 15) & ~15, ntiles = R16 / 16;
     if (T > 0 && coop_ok(R, exch, exch_bytes, B, T)) {
         const int n_st = (B + ROWS - 1) / ROWS;
         ProfScope prof(s, KC_GRU_BWD, 2.0 * B * T * 3 * R * R);
-        hipError_t e = hipMemsetAsync(exch, 0, gru_exchange_bytes(B, T, R), s);
-        if (e != hipSuccess) return (int)e;
+        if (!exch_clean) {
+            hipError_t e = hipMemsetAsync(exch, 0, gru_exchange_bytes(B, T, R), s);
+            if (e != hipSuccess) return (int)e;
+        }
         const dim3 grid(ntiles, coop_slots(ntiles, n_st));
         if ((3 * R >> 2) <= 152)
             hipLaunchKernelGGL(gru_bwd_coop_kernel<38>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,

@@ -194,7 +194,66 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
     }
 }
 
+// ---- Linear layers over a handful of rows (one row per graph) ------------------------------------------------
+// y[m][n] = b[n] + sum_k x[m][k] w[n][k] with M*N of a few ten thousand and K of 56..400: as a tiled MFMA product
+// this is 8-12 workgroups (or a split reduction plus its slab sum) whose cost is launch, prologue and epilogue,
+// 10-16 us on the dependent chain of the step.  Here one wave takes one output: lanes split k (16-byte coalesced
+// loads of both rows), partial sums meet in a fixed butterfly order, so results are reproducible.
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y, int ldy,
+                                                               int M, int N, int K4) {
+    const int lane = threadIdx.x & 63;
+    const long long out = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (out >= (long long)M * N) return;       // wave-uniform
+    const int m = (int)(out / N), n = (int)(out - (long long)m * N);
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)m * ldx);
+    const float4* wr = reinterpret_cast<const float4*>(w + (long long)n * (K4 * 4));
+    float acc = 0.f;
+    for (int k = lane; k < K4; k += 64) {
+        const float4 a = xr[k], c = wr[k];
+        acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) y[(long long)m * ldy + n] = acc + (b ? b[n] : 0.f);
+}
+
+// dx[m][k] = sum_n dy[m][n] w[n][k]: one wave per row m, lanes over k (coalesced rows of w), n in order.
+__global__ __launch_bounds__(64) void small_linear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, int lddx, int M, int N, int K) {
+    const int m = blockIdx.x, k = blockIdx.y * 64 + threadIdx.x;
+    if (k >= K) return;
+    const float* dr = dy + (long long)m * lddy;
+    float acc = 0.f;
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {      // four rows of w in flight per round trip
+        const float w0 = w[(long long)n * K + k], w1 = w[(long long)(n + 1) * K + k];
+        const float w2 = w[(long long)(n + 2) * K + k], w3 = w[(long long)(n + 3) * K + k];
+        acc = fmaf(dr[n], w0, acc); acc = fmaf(dr[n + 1], w1, acc); acc = fmaf(dr[n + 2], w2, acc); acc = fmaf(dr[n + 3], w3, acc);
+    }
+    for (; n < N; ++n) acc = fmaf(dr[n], w[(long long)n * K + k], acc);
+    dx[(long long)m * lddx + k] = acc;
+}
+
 }  // namespace
+
+int small_linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K % 4 || ldx % 4 || !aligned16(x) || !aligned16(w)) return PSVAE_E_ALIGN;
+    ProfScope prof(s, KC_HEAD, 2.0 * M * N * K);
+    const long long outs = (long long)M * N;
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, x, ldx, w, b, y, ldy, M, N, K / 4);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int small_linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K) {
+    if (M <= 0 || K <= 0) return 0;
+    ProfScope prof(s, KC_HEAD, 2.0 * M * N * K);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(M, (K + 63) / 64), dim3(64), 0, s, dy, lddy, w, dx, lddx, M, N, K);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
 
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z) {
     if (B == 0) return 0;

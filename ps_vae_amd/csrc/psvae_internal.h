@@ -124,6 +124,9 @@ __device__ __forceinline__ float gscale_at(const GScale& s, int k) {
     return k == 0 ? s.g[0] + g5 * s.w_pred : (k == 1 ? s.g[2] + s.g[1] + g5 * s.w_rec : (k == 2 ? s.g[3] + s.g[1] + g5 * s.w_rec : s.g[4] + g5 * s.w_kl));
 }
 #endif
+// Linear layers over a handful of rows (latent_to_rnn_hidden, W_mean/W_log_var): a wave per output instead of MFMA tiles
+int small_linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K);
+int small_linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K);
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z);
 int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
                  GScale gscale,
@@ -146,9 +149,11 @@ int link_softmax(hipStream_t s, const float* logits, float* probs, float* conf, 
 // `exch` (gru_exchange_bytes, 16-byte aligned, or NULL) enables the multi-CU recurrence
 size_t gru_exchange_bytes(int B, int T, int R);
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes);
+            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean = false);
 int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
-            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes);
+            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean = false);
+// zero the exchange buffer ahead of time (then pass exch_clean = true)
+int gru_exchange_clear(hipStream_t s, void* exch, size_t exch_bytes, int B, int T, int R);
 
 // ------------------------------------------------------------ optimiser
 int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count, float* partials,

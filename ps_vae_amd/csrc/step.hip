@@ -276,6 +276,16 @@ __global__ void split_mulv_kernel(const float* __restrict__ mulv, float* __restr
     lvar[t] = -fabsf(mulv[(size_t)b * 2 * Z + Z + k]);
 }
 
+// Linear layer over one row per graph: the wave-per-output kernel while the output is small (its cost is a
+// few microseconds of latency), the tiled MFMA product beyond.
+constexpr long long SMALL_LINEAR_OUTPUTS = 1 << 16;
+int rows_linear_fwd(hipStream_t st, const float* x, int ldx, const float* wt, const float* bias, float* y, int ldy,
+                    int M, int N, int K, float* scratch, size_t scratch_floats) {
+    if ((long long)M * N <= SMALL_LINEAR_OUTPUTS && K % 4 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(wt))
+        return small_linear_fwd(st, x, ldx, wt, bias, y, ldy, M, N, K);
+    return linear_fwd(st, x, ldx, wt, bias, y, ldy, M, N, K, 0, scratch, scratch_floats);
+}
+
 // Encoder half shared by the training step and psvae_encode: x0 .. mulv.
 int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, const psvae_batch& b, const Sz& s,
                     const WS& w, bool with_decoder_stack) {
@@ -296,10 +306,10 @@ int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, 
                              w.scratch, w.scratch_floats));
     }
     if (p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z) {
-        PSVAE_TRY(linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, 0, w.scratch, w.scratch_floats));
+        PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, w.scratch, w.scratch_floats));
     } else {
-        PSVAE_TRY(linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
-        PSVAE_TRY(linear_fwd(st, cond, s.G, p.lvar_w, p.lvar_b, w.mulv + s.Z, 2 * s.Z, s.B, s.Z, s.G, 0, w.scratch, w.scratch_floats));
+        PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, s.Z, s.G, w.scratch, w.scratch_floats));
+        PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.lvar_w, p.lvar_b, w.mulv + s.Z, 2 * s.Z, s.B, s.Z, s.G, w.scratch, w.scratch_floats));
     }
     return 0;
 }
@@ -340,6 +350,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     if (L) PSVAE_TRY(hand_over(st, s1, L->ev[0]));
     PSVAE_TRY(rows_gather(s1, b.pieces, 0, s.T, s.L, p.piece_emb, s.Dp, w.semb, s.BT));
     PSVAE_TRY(linear_fwd(s1, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch1, scf));
+    PSVAE_TRY(gru_exchange_clear(s1, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));   // long before z arrives
     // main: encoder and decoder-side GINE stacks, pooling, latent
     PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true));
     PSVAE_TRY(vae_head_fwd(st, w.mulv, b.eps, w.z, w.klrow, s.B, s.Z));
@@ -353,8 +364,8 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
     PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
     // lane 1: GRU + vocabulary logits + piece loss rows
-    PSVAE_TRY(linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, 0, w.scratch1, scf));
-    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes));
+    PSVAE_TRY(rows_linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, w.scratch1, scf));
+    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true));
     PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
     PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
     // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
@@ -393,11 +404,16 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     const GScale gs{loss_grads, loss_weights ? loss_weights[0] : 0.f, loss_weights ? loss_weights[1] : 0.f,
                     loss_weights ? loss_weights[2] : 0.f};
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[0])); PSVAE_TRY(hand_over(st, s2, L->ev[1])); }
+    // the recurrence's exchange buffer is zeroed on lane 2, off the piece branch's dependent chain
+    PSVAE_TRY(gru_exchange_clear(s2, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));
+    if (L && hipEventRecord(L->ev[14], s2) != hipSuccess) return (int)hipGetLastError();
     // --- lane 1: piece branch (cross-entropy, to_vocab, GRU, latent_to_rnn_hidden)
     PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
-    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes));
-    PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
+    if (L && hipStreamWaitEvent(s1, L->ev[14], 0) != hipSuccess) return (int)hipGetLastError();
+    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true));
+    if ((long long)s.B * s.Z <= SMALL_LINEAR_OUTPUTS) PSVAE_TRY(small_linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z));
+    else PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
     if (L && hipEventRecord(L->ev[2], s1) != hipSuccess) return (int)hipGetLastError();   // dz_piece, dsemb ready
     PSVAE_TRY(linear_bwd_w(s1, w.logits, s.ldl, 0, w.hseq, s.R, 0, 1, g.vocab_w, g.vocab_b, s.BT, s.V2, s.R, sc1, scf));
