@@ -218,21 +218,54 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __re
     if (lane == 0) y[(long long)m * ldy + n] = acc + (b ? b[n] : 0.f);
 }
 
-// dx[m][k] = sum_n dy[m][n] w[n][k]: one wave per row m, lanes over k (coalesced rows of w), n in order.
-__global__ __launch_bounds__(64) void small_linear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
-                                                             float* __restrict__ dx, int lddx, int M, int N, int K) {
-    const int m = blockIdx.x, k = blockIdx.y * 64 + threadIdx.x;
-    if (k >= K) return;
+// The same for a short reduction (K <= 64, e.g. latent_to_rnn_hidden with K = 56): a wave per output would leave
+// most lanes idle, so one THREAD takes one output and walks its K in order (x[m] is a broadcast read, the rows
+// of w are 16-byte loads from a matrix that sits in L1/L2).
+template <int K4MAX>
+__global__ __launch_bounds__(256) void small_linear_fwd_shortk_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                                      const float* __restrict__ b, float* __restrict__ y, int ldy,
+                                                                      int M, int N, int K4) {
+    const long long out = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool on = out < (long long)M * N;
+    const long long o = on ? out : 0;
+    const int m = (int)(o / N), n = (int)(o - (long long)m * N);
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)m * ldx);
+    const float4* wr = reinterpret_cast<const float4*>(w + (long long)n * (K4 * 4));
+    float4 c[K4MAX];
+#pragma unroll
+    for (int k = 0; k < K4MAX; ++k) c[k] = wr[min(k, K4 - 1)];     // all in flight at once
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < K4MAX; ++k) {
+        if (k < K4) {
+            const float4 a = xr[k];
+            acc = fmaf(a.x, c[k].x, acc); acc = fmaf(a.y, c[k].y, acc); acc = fmaf(a.z, c[k].z, acc); acc = fmaf(a.w, c[k].w, acc);
+        }
+    }
+    if (on) y[(long long)m * ldy + n] = acc + (b ? b[n] : 0.f);
+}
+
+// dx[m][k] = sum_n dy[m][n] w[n][k]: one block per row m; thread (slice q, column k) sums a quarter of the n range
+// in order with eight rows of w in flight, the four slices are added in slice order through LDS.
+__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int lddx, int M, int N, int K) {
+    __shared__ float part[4][64];
+    const int m = blockIdx.x, q = threadIdx.x >> 6, kk = threadIdx.x & 63, k = blockIdx.y * 64 + kk;
+    const int per = (N + 3) / 4, n0 = min(N, q * per), n1 = min(N, n0 + per);
     const float* dr = dy + (long long)m * lddy;
     float acc = 0.f;
-    int n = 0;
-    for (; n + 4 <= N; n += 4) {      // four rows of w in flight per round trip
-        const float w0 = w[(long long)n * K + k], w1 = w[(long long)(n + 1) * K + k];
-        const float w2 = w[(long long)(n + 2) * K + k], w3 = w[(long long)(n + 3) * K + k];
-        acc = fmaf(dr[n], w0, acc); acc = fmaf(dr[n + 1], w1, acc); acc = fmaf(dr[n + 2], w2, acc); acc = fmaf(dr[n + 3], w3, acc);
+    if (k < K) {
+        for (int n = n0; n < n1; n += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w[(long long)min(n + u, n1 - 1) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = n + u < n1 ? fmaf(dr[n + u], wv[u], acc) : acc;
+        }
     }
-    for (; n < N; ++n) acc = fmaf(dr[n], w[(long long)n * K + k], acc);
-    dx[(long long)m * lddx + k] = acc;
+    part[q][kk] = acc;
+    __syncthreads();
+    if (q == 0 && k < K) dx[(long long)m * lddx + k] = ((part[0][kk] + part[1][kk]) + part[2][kk]) + part[3][kk];
 }
 
 }  // namespace
@@ -242,7 +275,10 @@ int small_linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, con
     if (K % 4 || ldx % 4 || !aligned16(x) || !aligned16(w)) return PSVAE_E_ALIGN;
     ProfScope prof(s, KC_HEAD, 2.0 * M * N * K);
     const long long outs = (long long)M * N;
-    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, x, ldx, w, b, y, ldy, M, N, K / 4);
+    if (K <= 64)
+        hipLaunchKernelGGL(small_linear_fwd_shortk_kernel<16>, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, s, x, ldx, w, b, y, ldy, M, N, K / 4);
+    else
+        hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, s, x, ldx, w, b, y, ldy, M, N, K / 4);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -250,7 +286,7 @@ int small_linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, con
 int small_linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K) {
     if (M <= 0 || K <= 0) return 0;
     ProfScope prof(s, KC_HEAD, 2.0 * M * N * K);
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(M, (K + 63) / 64), dim3(64), 0, s, dy, lddy, w, dx, lddx, M, N, K);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(M, (K + 63) / 64), dim3(256), 0, s, dy, lddy, w, dx, lddx, M, N, K);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
