@@ -239,10 +239,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) float sB[2][BK][Pitch<BT>::value];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int z = blockIdx.z, seg = z / p.splits, sp = z - seg * p.splits;
+    // Workgroups are handed to the 8 XCDs round-robin in dispatch order, and each XCD has an L2 of its own.
+    // Tiles that read the same operand panel (one row of tiles; all tiles of one reduction slab) are therefore
+    // renumbered so that they run on ONE XCD, next to each other in time: XCD k works through the k-th
+    // contiguous eighth of the tile list (z slowest, then tile row, tile column fastest), and a panel is
+    // fetched into one L2 once instead of into five of them.
+    const unsigned gxy = gridDim.x * gridDim.y, nb = gxy * gridDim.z;
+    const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = bid & 7u, per = nb >> 3, rem = nb & 7u;
+    const unsigned tile = xcd * per + min(xcd, rem) + (bid >> 3);
+    const int z = tile / gxy, txy = tile - z * gxy;
+    const int tx = txy / gridDim.y, ty = txy - tx * gridDim.y;
+    const int seg = z / p.splits, sp = z - seg * p.splits;
     const float* A = p.A + seg * p.seg_a;
     const float* B = p.B + seg * p.seg_b;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = tx * BM, n0 = ty * BN;
     const int rbeg = sp * p.rchunk;
     const int rend = min(p.R, rbeg + p.rchunk);
     const int nk = (rend - rbeg + BK - 1) / BK;
