@@ -118,14 +118,23 @@ __device__ __forceinline__ void store_quad(float (*s)[Pitch<T>::value], float4 v
 // add to every output, so a tile that overhangs it has those elements zeroed.  A tile that overhangs the
 // OUTPUT range is written as loaded: row o of an operand only ever meets output row (column) o, rows past the
 // matrix produce outputs the epilogue never writes, and their loads come from clamped, valid addresses.  The
-// one output index with a value of its own is the ones column (bias-gradient trick), filled in by the flagged
-// path too.  The branch is uniform per workgroup and K-step.
+// one output index with a value of its own is the ones column (bias-gradient trick).  The branch is uniform
+// per workgroup and K-step.
+// The quad that holds the ones column gets its 1 by four selects (ones_col = -1 matches no quad), so the tile
+// with that column needs the flagged path no more often than any other tile.
+template <bool T>
+__device__ __forceinline__ float4 patch_ones(float4 v, const TileGeo& g, int q) {
+    if (T) {
+        const int d = g.ones_col - (g.o0 + ((q & 15) << 2));
+        v.x = d == 0 ? 1.f : v.x; v.y = d == 1 ? 1.f : v.y; v.z = d == 2 ? 1.f : v.z; v.w = d == 3 ? 1.f : v.w;
+    }
+    return v;
+}
 template <bool T>
 __device__ __forceinline__ void store_stage(float (*s)[Pitch<T>::value], const Stage& st, const TileGeo& g, int r0, int tid) {
-    const bool ones_here = T && g.ones_col >= g.o0 && g.ones_col < g.o0 + BM;
-    if (r0 + BK <= g.r_lim && !ones_here) {
-        store_quad<T>(s, st.v0, tid);
-        store_quad<T>(s, st.v1, tid + 256);
+    if (r0 + BK <= g.r_lim) {
+        store_quad<T>(s, patch_ones<T>(st.v0, g, tid), tid);
+        store_quad<T>(s, patch_ones<T>(st.v1, g, tid + 256), tid + 256);
     } else {
         store_quad<T>(s, apply_flags(st.v0, quad_flags<T>(g, r0, tid)), tid);
         store_quad<T>(s, apply_flags(st.v1, quad_flags<T>(g, r0, tid + 256)), tid + 256);
