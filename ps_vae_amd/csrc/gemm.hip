@@ -443,7 +443,7 @@ Plan plan_splits(int M, int N, int R, int nseg) {
     Plan pl{1, (int)round_up(R > 0 ? R : 1, BK)};
     if (tiles >= 200 || R <= 4 * BK) return pl;
     static const int target = [] { const char* e = getenv("PSVAE_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
-    int want = (int)((target + tiles - 1) / tiles);
+    int want = (int)(target / tiles);      // rounded down: 512 workgroups or fewer fit the GPU two per CU at once
     int maxs = R / (4 * BK);
     if (want > maxs) want = maxs;
     if (want <= 1) return pl;
