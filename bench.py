@@ -261,6 +261,8 @@ def main():
         j = i % n_distinct
         pending[i] = reducer.reduce_denoms(local_denoms[j], out=batches[j]['_native'].denoms, async_op=True)[1]
 
+    unit = model.unit_grad()       # loss.backward(unit): no fill / copy launches for the implicit gradient of 1
+
     def step(i):
         batch = batches[i % n_distinct]
         if dist_on:
@@ -272,7 +274,7 @@ def main():
         eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
         opt.zero_grad()
         loss = model.training_step(batch, eps=eps)
-        loss.backward()
+        loss.backward(unit)
         if dist_on:
             if shared_gpu:
                 torch.cuda.synchronize()

@@ -82,7 +82,11 @@ class _StepFn(torch.autograd.Function):
             g = model._g6
             if g_total is None:
                 return None, None, None, None, None
-            g[5:6].copy_(g_total.reshape(1))
+            unit = model._unit
+            if unit is not None and g_total.data_ptr() == unit[0].data_ptr():
+                g = unit[1]            # `total.backward(model.unit_grad())`: the constant vector, no copy kernel
+            else:
+                g[5:6].copy_(g_total.reshape(1))
         else:
             g = g.contiguous()
             if g_total is not None:
@@ -123,6 +127,7 @@ class PSVAEModel(nn.Module):
         self._trigger = None
         self._last_ws = None
         self._g6 = None
+        self._unit = None
         self._early_events = None
         self._dims = self._make_dims()
 
@@ -285,6 +290,18 @@ class PSVAEModel(nn.Module):
         golden = nb.blob[goff:goff + S].long()
         edge_accu = (pair_logits.argmax(-1) == golden).sum().item() / max(S, 1)
         return piece_accu, edge_accu
+
+    def unit_grad(self):
+        """The scalar 1.0 on the model's device, for `total.backward(model.unit_grad())`: autograd then launches no
+        fill kernel for the implicit gradient and the step's backward recognises the tensor and uses a constant
+        upstream-gradient vector instead of copying the scalar into one (two tiny dependent launches per step).
+        The tensor must not be modified."""
+        dev = self._flat.device if self._flat is not None else next(self.parameters()).device
+        if self._unit is None or self._unit[0].device != dev:
+            g6 = torch.zeros(6, dtype=torch.float32, device=dev)
+            g6[5] = 1.0
+            self._unit = (torch.ones((), dtype=torch.float32, device=dev), g6)
+        return self._unit[0]
 
     def recurrence_gave_up(self):
         """True if a workgroup of the multi-CU GRU recurrence of the most recent step stopped waiting for its

@@ -107,7 +107,7 @@ def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3
         for batch in train_loader:
             opt.zero_grad()
             loss = model.training_step(to_device(batch, device))
-            loss.backward()
+            loss.backward(model.unit_grad())
             opt.step()
             model.global_step += 1
         rec = validate(model, valid_loader, device)

@@ -239,3 +239,12 @@ def test_training_step_total_equals_weighted_loss():
     g_b = model.flat_buffers()[1].clone()
     assert abs(float(total_a.detach()) - float(total_b.detach())) <= 1e-6 * abs(float(total_a.detach()))
     check_close(g_b, g_a, 'gradients via fused total', rtol=1e-5, atol_scale=1e-6)
+    # `backward(model.unit_grad())` takes the constant upstream-gradient vector: same gradients bit for bit
+    model.zero_grad()
+    total_c = model.training_step(batch, eps=eps)
+    total_c.backward(model.unit_grad())
+    assert torch.equal(model.flat_buffers()[1], g_b)
+    model.zero_grad()
+    total_d = model.training_step(batch, eps=eps)
+    total_d.backward(torch.full((), 0.5, device='cuda:0'))       # any other gradient still goes through the copy
+    check_close(model.flat_buffers()[1], 0.5 * g_b, 'gradients for an upstream gradient of 0.5', rtol=1e-5, atol_scale=1e-6)
