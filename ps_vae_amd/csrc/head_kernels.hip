@@ -96,6 +96,92 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(float* __restrict__
     }
 }
 
+// Last layer of the link scorer (Linear(P -> 4), src/modules/vae_piece_decoder.py:42-46,110) together with its
+// cross-entropy (:115): with four outputs per row the product is a handful of dot products, not a tile problem.
+// A wave keeps its share of the four weight rows in registers (NCH float4 per row and lane) and walks over rows
+// of x: forward = 4 dot products, bias, log-sum-exp and the row's loss; backward = softmax gradient (left in
+// `logits` for the weight gradient) and dx = dlogits W.  One launch each instead of product + slab sum + loss
+// (forward) and loss gradient + product (backward).
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
+
+template <int NCH>
+__device__ __forceinline__ void load_w4(const float* __restrict__ w, int P4, int lane, float4 (&wr)[4][NCH]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = lane + 64 * j;
+            float4 v = reinterpret_cast<const float4*>(w + (long long)c * 4 * P4)[min(idx, P4 - 1)];   // clamped, unconditional
+            if (idx >= P4) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            wr[c][j] = v;
+        }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void pair_head_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const int32_t* __restrict__ gold,
+                                                            float* __restrict__ logits, float* __restrict__ row_loss,
+                                                            float* __restrict__ lse_out, int S, int P4) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    float4 wr[4][NCH];
+    load_w4<NCH>(w, P4, lane, wr);
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < S; r += nw) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (long long)r * ldx);
+        float4 xv[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) xv[j] = xr[min(lane + 64 * j, P4 - 1)];      // surplus chunks meet zero weights
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            a0 += dot4(xv[j], wr[0][j]); a1 += dot4(xv[j], wr[1][j]); a2 += dot4(xv[j], wr[2][j]); a3 += dot4(xv[j], wr[3][j]);
+        }
+        a0 = wave_sum(a0) + b0; a1 = wave_sum(a1) + b1; a2 = wave_sum(a2) + b2; a3 = wave_sum(a3) + b3;
+        const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+        const float lse = mx + logf(((expf(a0 - mx) + expf(a1 - mx)) + expf(a2 - mx)) + expf(a3 - mx));
+        if (lane == 0) {
+            reinterpret_cast<float4*>(logits)[r] = make_float4(a0, a1, a2, a3);
+            const int tg = gold[r];
+            lse_out[r] = lse;
+            row_loss[r] = lse - (tg == 0 ? a0 : (tg == 1 ? a1 : (tg == 2 ? a2 : a3)));
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void pair_head_bwd_kernel(float* __restrict__ logits, const float* __restrict__ lse,
+                                                            const int32_t* __restrict__ gold, const float* __restrict__ w,
+                                                            const GScale gscale, const float* __restrict__ denoms,
+                                                            float* __restrict__ dx, int lddx, int S, int P4) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    float4 wr[4][NCH];
+    load_w4<NCH>(w, P4, lane, wr);
+    const float scale = gscale_at(gscale, 2) / denoms[1];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < S; r += nw) {
+        const float4 lg = reinterpret_cast<const float4*>(logits)[r];
+        const float l = lse[r];
+        const int tg = gold[r];
+        const float d0 = (expf(lg.x - l) - (tg == 0 ? 1.f : 0.f)) * scale, d1 = (expf(lg.y - l) - (tg == 1 ? 1.f : 0.f)) * scale;
+        const float d2 = (expf(lg.z - l) - (tg == 2 ? 1.f : 0.f)) * scale, d3 = (expf(lg.w - l) - (tg == 3 ? 1.f : 0.f)) * scale;
+        if (lane == 0) reinterpret_cast<float4*>(logits)[r] = make_float4(d0, d1, d2, d3);
+        float4* out = reinterpret_cast<float4*>(dx + (long long)r * lddx);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < P4) {
+                float4 v;
+                v.x = fmaf(d3, wr[3][j].x, fmaf(d2, wr[2][j].x, fmaf(d1, wr[1][j].x, d0 * wr[0][j].x)));
+                v.y = fmaf(d3, wr[3][j].y, fmaf(d2, wr[2][j].y, fmaf(d1, wr[1][j].y, d0 * wr[0][j].y)));
+                v.z = fmaf(d3, wr[3][j].z, fmaf(d2, wr[2][j].z, fmaf(d1, wr[1][j].z, d0 * wr[0][j].z)));
+                v.w = fmaf(d3, wr[3][j].w, fmaf(d2, wr[2][j].w, fmaf(d1, wr[1][j].w, d0 * wr[0][j].w)));
+                out[idx] = v;
+            }
+        }
+    }
+}
+
 __global__ void mse_fwd_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ gold,
                                float* __restrict__ row, int B, int P) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,6 +416,35 @@ int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* ta
     { ProfScope prof(s, KC_CE, 8.0 * rows * classes);
     hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3(blocks), dim3(256), 0, s, logits_inout, ld, target, tstride, toffset,
                        rows_per_group, rows, classes, ignore_index, lse, gscale, gidx, denoms, didx);
+    }
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+bool pair_head_supported(const float* x, int ldx, const float* w, const float* dx, int lddx, int P) {
+    return P > 0 && P % 4 == 0 && P <= 5 * 256 && ldx % 4 == 0 && lddx % 4 == 0 && aligned16(x) && aligned16(w) && (!dx || aligned16(dx));
+}
+int pair_head_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* bias, const int32_t* gold,
+                  float* logits, float* row_loss, float* lse, int S, int P) {
+    if (S == 0) return 0;
+    if (!pair_head_supported(x, ldx, w, nullptr, 4, P) || !aligned16(logits)) return PSVAE_E_ALIGN;
+    const int P4 = P / 4, nch = (P4 + 63) / 64;
+    const int blocks = (S + 3) / 4 < 1024 ? (S + 3) / 4 : 1024;
+    { ProfScope prof(s, KC_CE, 4.0 * S * (P + 4));
+    if (nch <= 3) hipLaunchKernelGGL(pair_head_fwd_kernel<3>, dim3(blocks), dim3(256), 0, s, x, ldx, w, bias, gold, logits, row_loss, lse, S, P4);
+    else hipLaunchKernelGGL(pair_head_fwd_kernel<5>, dim3(blocks), dim3(256), 0, s, x, ldx, w, bias, gold, logits, row_loss, lse, S, P4);
+    }
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int pair_head_bwd(hipStream_t s, float* logits_inout, const float* lse, const int32_t* gold, const float* w, GScale gscale,
+                  const float* denoms, float* dx, int lddx, int S, int P) {
+    if (S == 0) return 0;
+    if (!pair_head_supported(dx, lddx, w, dx, lddx, P) || !aligned16(logits_inout)) return PSVAE_E_ALIGN;
+    const int P4 = P / 4, nch = (P4 + 63) / 64;
+    const int blocks = (S + 3) / 4 < 1024 ? (S + 3) / 4 : 1024;
+    { ProfScope prof(s, KC_CE, 4.0 * S * (P + 8));
+    if (nch <= 3) hipLaunchKernelGGL(pair_head_bwd_kernel<3>, dim3(blocks), dim3(256), 0, s, logits_inout, lse, gold, w, gscale, denoms, dx, lddx, S, P4);
+    else hipLaunchKernelGGL(pair_head_bwd_kernel<5>, dim3(blocks), dim3(256), 0, s, logits_inout, lse, gold, w, gscale, denoms, dx, lddx, S, P4);
     }
     PSVAE_LAUNCH_CHECK();
     return 0;

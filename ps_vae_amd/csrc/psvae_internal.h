@@ -136,6 +136,13 @@ int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* ta
 int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, const float* lse,
                    GScale gscale, int gidx, const float* denoms, int didx);
+// Linear(P -> 4) + cross-entropy of the link scorer in one launch each way (wave per row, weights in registers).
+// forward: logits [S,4], lse, row loss; backward: logits <- dL/dlogits in place, dx [S, lddx] = dlogits W.
+bool pair_head_supported(const float* x, int ldx, const float* w, const float* dx, int lddx, int P);
+int pair_head_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* bias, const int32_t* gold,
+                  float* logits, float* row_loss, float* lse, int S, int P);
+int pair_head_bwd(hipStream_t s, float* logits_inout, const float* lse, const int32_t* gold, const float* w, GScale gscale,
+                  const float* denoms, float* dx, int lddx, int S, int P);
 int mse_fwd(hipStream_t s, const float* pred, int ldp, const float* gold, float* row, int B, int P);
 int mse_bwd(hipStream_t s, const float* pred, int ldp, const float* gold, GScale gscale, const float* denoms,
             float* dpred, int B, int P);

@@ -361,8 +361,12 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s2, s.P2, p.sc_w2, p.sc_b2, w.s3, s.P, s.S, s.P, s.P2, 0, w.scratch, scf));
-    PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
-    PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
+    if (pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P)) {
+        PSVAE_TRY(pair_head_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, b.pair_gold, w.slog, w.rowloss_e, w.lse_e, s.S, s.P));
+    } else {
+        PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
+        PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
+    }
     // lane 1: GRU + vocabulary logits + piece loss rows
     PSVAE_TRY(rows_linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, w.scratch1, scf));
     PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true));
@@ -438,10 +442,12 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
         PSVAE_TRY(linear_bwd_w(s2, w.dq1, s.Hp, 0, w.z, s.Z, 0, 1, g.pred_w0, g.pred_b0, s.B, s.Hp, s.Z, sc2, scf));
     }
     // --- main: link scorer input-gradient chain; its weight gradients follow on lane 2
-    PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
+    const bool fused_pair_head = pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    if (fused_pair_head) PSVAE_TRY(pair_head_bwd(st, w.slog, w.lse_e, b.pair_gold, p.sc_w3, gs, b.denoms, w.ds3, s.P, s.S, s.P));
+    else PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
     PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
-    PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
+    if (!fused_pair_head) PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[5]));
     PSVAE_TRY(linear_bwd_w(s2, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc2, scf));
     PSVAE_TRY(linear_bwd_x(st, w.ds3, s.P, p.sc_w2, w.ds2, s.P2, s.S, s.P, s.P2, w.s2, s.P2, 0));
