@@ -127,24 +127,35 @@ __global__ __launch_bounds__(256) void pair_head_fwd_kernel(const float* __restr
     float4 wr[4][NCH];
     load_w4<NCH>(w, P4, lane, wr);
     const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
-    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < S; r += nw) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (long long)r * ldx);
-        float4 xv[NCH];
+    // rows in groups of RB: all their loads go out before the first reduction (one memory round trip per group)
+    constexpr int RB = 4;
+    for (int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RB; r0 < S; r0 += nw * RB) {
+        float4 xv[RB][NCH];
+        int tgs[RB];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) xv[j] = xr[min(lane + 64 * j, P4 - 1)];      // surplus chunks meet zero weights
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int i = 0; i < RB; ++i) {
+            const int r = min(r0 + i, S - 1);
+            const float4* xr = reinterpret_cast<const float4*>(x + (long long)r * ldx);
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            a0 += dot4(xv[j], wr[0][j]); a1 += dot4(xv[j], wr[1][j]); a2 += dot4(xv[j], wr[2][j]); a3 += dot4(xv[j], wr[3][j]);
+            for (int j = 0; j < NCH; ++j) xv[i][j] = xr[min(lane + 64 * j, P4 - 1)];      // surplus chunks meet zero weights
+            tgs[i] = gold[r];
         }
-        a0 = wave_sum(a0) + b0; a1 = wave_sum(a1) + b1; a2 = wave_sum(a2) + b2; a3 = wave_sum(a3) + b3;
-        const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-        const float lse = mx + logf(((expf(a0 - mx) + expf(a1 - mx)) + expf(a2 - mx)) + expf(a3 - mx));
-        if (lane == 0) {
-            reinterpret_cast<float4*>(logits)[r] = make_float4(a0, a1, a2, a3);
-            const int tg = gold[r];
-            lse_out[r] = lse;
-            row_loss[r] = lse - (tg == 0 ? a0 : (tg == 1 ? a1 : (tg == 2 ? a2 : a3)));
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                a0 += dot4(xv[i][j], wr[0][j]); a1 += dot4(xv[i][j], wr[1][j]); a2 += dot4(xv[i][j], wr[2][j]); a3 += dot4(xv[i][j], wr[3][j]);
+            }
+            a0 = wave_sum(a0) + b0; a1 = wave_sum(a1) + b1; a2 = wave_sum(a2) + b2; a3 = wave_sum(a3) + b3;
+            const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+            const float lse = mx + logf(((expf(a0 - mx) + expf(a1 - mx)) + expf(a2 - mx)) + expf(a3 - mx));
+            const int r = r0 + i, tg = tgs[i];
+            if (lane == 0 && r < S) {
+                reinterpret_cast<float4*>(logits)[r] = make_float4(a0, a1, a2, a3);
+                lse_out[r] = lse;
+                row_loss[r] = lse - (tg == 0 ? a0 : (tg == 1 ? a1 : (tg == 2 ? a2 : a3)));
+            }
         }
     }
 }
@@ -354,6 +365,108 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
     if (q == 0 && k < K) dx[(long long)m * lddx + k] = ((part[0][kk] + part[1][kk]) + part[2][kk]) + part[3][kk];
 }
 
+// W_mean / W_log_var (one [2Z, G] matrix) and rsample in one launch: a block of 16 waves per graph.  Each wave
+// takes every sixteenth output of the 2Z, eight of them per round with all their weight loads in flight at once
+// (lanes split the G inputs, same order of additions as small_linear_fwd_kernel); the results meet in LDS, then
+// the first wave does what vae_head_fwd_kernel does.  Saves a dependent launch.
+template <int NCH>
+__global__ __launch_bounds__(1024) void latent_head_fwd_kernel(const float* __restrict__ cond, int ldc, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ eps,
+                                                               float* __restrict__ mulv, float* __restrict__ z,
+                                                               float* __restrict__ klrow, int Z, int G4) {
+    __shared__ float sm[1024];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, N = 2 * Z;
+    const float4* xr = reinterpret_cast<const float4*>(cond + (long long)b * ldc);
+    float4 xv[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        xv[j] = xr[min(lane + 64 * j, G4 - 1)];
+        if (lane + 64 * j >= G4) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int o0 = wave; o0 < N; o0 += 16 * 8) {
+        float4 wv[8][NCH];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                wv[u][j] = reinterpret_cast<const float4*>(w + (long long)min(o0 + 16 * u, N - 1) * (G4 * 4))[min(lane + 64 * j, G4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                acc = fmaf(xv[j].x, wv[u][j].x, acc); acc = fmaf(xv[j].y, wv[u][j].y, acc);
+                acc = fmaf(xv[j].z, wv[u][j].z, acc); acc = fmaf(xv[j].w, wv[u][j].w, acc);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+            const int o = o0 + 16 * u;
+            if (lane == 0 && o < N) sm[o] = acc + bias[o];
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < N; o += 1024) mulv[(long long)b * N + o] = sm[o];
+    if (wave == 0) {
+        float sum = 0.f;
+        for (int k = lane; k < Z; k += 64) {
+            const float m = sm[k], lv = -fabsf(sm[Z + k]);
+            sum += 1.0f + lv - m * m - expf(lv);
+            z[(long long)b * Z + k] = m + expf(lv * 0.5f) * eps[(long long)b * Z + k];
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) klrow[b] = sum;
+    }
+}
+
+// vae_head_bwd_kernel and the input gradient of [W_mean; W_log_var] in one launch: block (graph, 64 columns of
+// d_cond).  Every block forms the graph's 2Z values of d_mulv in LDS (block column 0 also stores them for the
+// weight gradient), then sums its columns as small_linear_dx_kernel does.
+__global__ __launch_bounds__(256) void latent_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
+                                                              const float* __restrict__ dz0, const float* __restrict__ dz1,
+                                                              const float* __restrict__ dz2, const GScale gscale,
+                                                              const float* __restrict__ denoms, const float* __restrict__ w,
+                                                              float* __restrict__ dmulv, float* __restrict__ dcond, int ldd,
+                                                              int Z, int G) {
+    __shared__ float sd[1024];
+    __shared__ float part[4][64];
+    const int b = blockIdx.x, N = 2 * Z;
+    // this thread's column of the weights (first 32 rows of its slice) is requested before anything else: it
+    // does not depend on d_mulv, so its latency overlaps the loads and the arithmetic of the first phase
+    const int q = threadIdx.x >> 6, kk = threadIdx.x & 63, k = blockIdx.y * 64 + kk, kc = min(k, G - 1);
+    const int per = (N + 3) / 4, n0 = min(N, q * per), n1 = min(N, n0 + per);
+    float wpre[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wpre[u] = w[(long long)min(n0 + u, N - 1) * G + kc];
+    for (int k = threadIdx.x; k < Z; k += 256) {
+        const long long t = (long long)b * Z + k;
+        const float gk = gscale_at(gscale, 3) / denoms[2];
+        const float m = mulv[(long long)b * N + k], raw = mulv[(long long)b * N + Z + k];
+        float d = dz0[t];
+        if (dz1) d += dz1[t];
+        if (dz2) d += dz2[t];
+        const float lv = -fabsf(raw);
+        const float dmu = d + gk * m;
+        const float dlv = d * eps[t] * 0.5f * expf(lv * 0.5f) + gk * (-0.5f) * (1.0f - expf(lv));
+        const float sgn = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
+        sd[k] = dmu; sd[Z + k] = -sgn * dlv;
+        if (blockIdx.y == 0) { dmulv[(long long)b * N + k] = dmu; dmulv[(long long)b * N + Z + k] = -sgn * dlv; }
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc = n0 + u < n1 ? fmaf(sd[min(n0 + u, N - 1)], wpre[u], acc) : acc;
+    for (int n = n0 + 32; n < n1; n += 8) {          // slices longer than 32 rows (2Z > 128)
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(long long)min(n + u, n1 - 1) * G + kc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = n + u < n1 ? fmaf(sd[n + u], wv[u], acc) : acc;
+    }
+    part[q][kk] = acc;
+    __syncthreads();
+    if (q == 0 && k < G) dcond[(long long)b * ldd + k] = ((part[0][kk] + part[1][kk]) + part[2][kk]) + part[3][kk];
+}
+
 }  // namespace
 
 int small_linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K) {
@@ -377,6 +490,30 @@ int small_linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w,
     return 0;
 }
 
+bool latent_head_supported(const float* cond, int ldc, const float* w, int Z, int G) {
+    return Z > 0 && 2 * Z <= 1024 && G > 0 && G % 4 == 0 && G <= 1024 && ldc % 4 == 0 && aligned16(cond) && aligned16(w);
+}
+int latent_head_fwd(hipStream_t s, const float* cond, int ldc, const float* w, const float* bias, const float* eps,
+                    float* mulv, float* z, float* klrow, int B, int Z, int G) {
+    if (B == 0) return 0;
+    if (!latent_head_supported(cond, ldc, w, Z, G)) return PSVAE_E_ALIGN;
+    ProfScope prof(s, KC_HEAD, 2.0 * B * 2 * Z * G);
+    const int G4 = G / 4;
+    if (G4 <= 128) hipLaunchKernelGGL(latent_head_fwd_kernel<2>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4);
+    else hipLaunchKernelGGL(latent_head_fwd_kernel<4>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+int latent_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
+                    GScale gscale, const float* denoms, const float* w, float* dmulv, float* dcond, int ldd, int B, int Z, int G) {
+    if (B == 0) return 0;
+    if (2 * Z > 1024) return PSVAE_E_SHAPE;
+    ProfScope prof(s, KC_HEAD, 2.0 * B * 2 * Z * G);
+    hipLaunchKernelGGL(latent_head_bwd_kernel, dim3(B, (G + 63) / 64), dim3(256), 0, s, mulv, eps, dz0, dz1, dz2, gscale, denoms, w,
+                       dmulv, dcond, ldd, Z, G);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z) {
     if (B == 0) return 0;
     { ProfScope prof(s, KC_HEAD, 0);
@@ -428,7 +565,7 @@ int pair_head_fwd(hipStream_t s, const float* x, int ldx, const float* w, const 
     if (S == 0) return 0;
     if (!pair_head_supported(x, ldx, w, nullptr, 4, P) || !aligned16(logits)) return PSVAE_E_ALIGN;
     const int P4 = P / 4, nch = (P4 + 63) / 64;
-    const int blocks = (S + 3) / 4 < 1024 ? (S + 3) / 4 : 1024;
+    const int blocks = (S + 15) / 16 < 1024 ? (S + 15) / 16 : 1024;      // a wave takes 4 rows per round
     { ProfScope prof(s, KC_CE, 4.0 * S * (P + 4));
     if (nch <= 3) hipLaunchKernelGGL(pair_head_fwd_kernel<3>, dim3(blocks), dim3(256), 0, s, x, ldx, w, bias, gold, logits, row_loss, lse, S, P4);
     else hipLaunchKernelGGL(pair_head_fwd_kernel<5>, dim3(blocks), dim3(256), 0, s, x, ldx, w, bias, gold, logits, row_loss, lse, S, P4);

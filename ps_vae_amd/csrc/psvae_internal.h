@@ -127,6 +127,13 @@ __device__ __forceinline__ float gscale_at(const GScale& s, int k) {
 // Linear layers over a handful of rows (latent_to_rnn_hidden, W_mean/W_log_var): a wave per output instead of MFMA tiles
 int small_linear_fwd(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K);
 int small_linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K);
+// [W_mean; W_log_var] (one [2Z, G] matrix) fused with rsample (forward: mulv, z, KL rows) and with its input
+// gradient (backward: d_mulv, d_cond): one launch each instead of two on the step's dependent chain
+bool latent_head_supported(const float* cond, int ldc, const float* w, int Z, int G);
+int latent_head_fwd(hipStream_t s, const float* cond, int ldc, const float* w, const float* bias, const float* eps,
+                    float* mulv, float* z, float* klrow, int B, int Z, int G);
+int latent_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
+                    GScale gscale, const float* denoms, const float* w, float* dmulv, float* dcond, int ldd, int B, int Z, int G);
 int vae_head_fwd(hipStream_t s, const float* mulv, const float* eps, float* z, float* klrow, int B, int Z);
 int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,
                  GScale gscale,

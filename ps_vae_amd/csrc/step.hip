@@ -288,7 +288,7 @@ int rows_linear_fwd(hipStream_t st, const float* x, int ldx, const float* wt, co
 
 // Encoder half shared by the training step and psvae_encode: x0 .. mulv.
 int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, const psvae_batch& b, const Sz& s,
-                    const WS& w, bool with_decoder_stack) {
+                    const WS& w, bool with_decoder_stack, bool with_rsample) {
     PSVAE_TRY(embed3_gather(st, b.atom_id, b.piece_id, b.pos_id, p.atom_emb, p.piece_emb, p.pos_emb, s.Da, s.Dp, s.Dq, w.X0, s.n));
     const float* cond = b.conds ? b.conds : w.cond;
     Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
@@ -305,12 +305,16 @@ int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, 
         PSVAE_TRY(linear_fwd(st, w.pooled, s.te * s.H, p.enc_lin_w, p.enc_lin_b, w.cond, s.G, s.B, s.G, s.te * s.H, 0,
                              w.scratch, w.scratch_floats));
     }
-    if (p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z) {
+    const bool adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z;
+    if (with_rsample && adjacent && latent_head_supported(cond, s.G, p.mean_w, s.Z, s.G))    // mulv, z and the KL rows at once
+        return latent_head_fwd(st, cond, s.G, p.mean_w, p.mean_b, b.eps, w.mulv, w.z, w.klrow, s.B, s.Z, s.G);
+    if (adjacent) {
         PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, w.scratch, w.scratch_floats));
     } else {
         PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, s.Z, s.G, w.scratch, w.scratch_floats));
         PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.lvar_w, p.lvar_b, w.mulv + s.Z, 2 * s.Z, s.B, s.Z, s.G, w.scratch, w.scratch_floats));
     }
+    if (with_rsample) PSVAE_TRY(vae_head_fwd(st, w.mulv, b.eps, w.z, w.klrow, s.B, s.Z));
     return 0;
 }
 
@@ -352,8 +356,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     PSVAE_TRY(linear_fwd(s1, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch1, scf));
     PSVAE_TRY(gru_exchange_clear(s1, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));   // long before z arrives
     // main: encoder and decoder-side GINE stacks, pooling, latent
-    PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true));
-    PSVAE_TRY(vae_head_fwd(st, w.mulv, b.eps, w.z, w.klrow, s.B, s.Z));
+    PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true, true));
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[1])); PSVAE_TRY(hand_over(st, s2, L->ev[2])); }
     // (the scorer, the longest of the three branches, is queued first)
     // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
@@ -462,16 +465,20 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     // --- latent head and encoder.linear: needs the three parts of dL/dz
     if (L && (hipStreamWaitEvent(st, L->ev[2], 0) != hipSuccess || hipStreamWaitEvent(st, L->ev[3], 0) != hipSuccess))
         return (int)hipGetLastError();
-    if (dec_only) PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz_piece, w.dz_pair, b.d_z, gs, b.denoms, w.dmulv, s.B, s.Z));
-    else PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, w.dz, w.dz_piece, w.dz_pair, gs, b.denoms, w.dmulv, s.B, s.Z));
     float* dcond = dec_only ? b.d_conds : w.dcond;
     const bool head_adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z &&
                                g.lvar_w == g.mean_w + (size_t)s.Z * s.G && g.lvar_b == g.mean_b + s.Z;
+    const bool fused_head = head_adjacent && 2 * s.Z <= 1024;    // d_mulv and d_cond in one launch
+    const float* dz_a = dec_only ? w.dz_piece : w.dz;
+    const float* dz_b = dec_only ? w.dz_pair : w.dz_piece;
+    const float* dz_c = dec_only ? b.d_z : w.dz_pair;
+    if (fused_head) PSVAE_TRY(latent_head_bwd(st, w.mulv, b.eps, dz_a, dz_b, dz_c, gs, b.denoms, p.mean_w, w.dmulv, dcond, s.G, s.B, s.Z, s.G));
+    else PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, dz_a, dz_b, dz_c, gs, b.denoms, w.dmulv, s.B, s.Z));
     // (the weight gradients of these small layers go to lane 2: nothing on the chain waits for them)
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[12]));
     if (head_adjacent) {
         PSVAE_TRY(linear_bwd_w(s2, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc2, scf));
-        PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
+        if (!fused_head) PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
     } else {
         PSVAE_TRY(linear_bwd_w(s2, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, s.Z, s.G, sc2, scf));
         PSVAE_TRY(linear_bwd_w(s2, w.dmulv + s.Z, 2 * s.Z, 0, cond, s.G, 0, 1, g.lvar_w, g.lvar_b, s.B, s.Z, s.G, sc2, scf));
@@ -570,7 +577,7 @@ extern "C" int psvae_encode(const psvae_dims* dims, const psvae_params* params, 
     WS w;
     if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    PSVAE_TRY(encoder_to_mulv(st, *dims, *params, *batch, s, w, false));
+    PSVAE_TRY(encoder_to_mulv(st, *dims, *params, *batch, s, w, false, false));
     hipLaunchKernelGGL(split_mulv_kernel, dim3((s.B * s.Z + 255) / 256), dim3(256), 0, st, w.mulv, z_mean, z_log_var, s.B, s.Z);
     PSVAE_LAUNCH_CHECK();
     return 0;
