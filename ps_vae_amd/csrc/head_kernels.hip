@@ -225,10 +225,21 @@ __global__ __launch_bounds__(256) void losses_finalize_kernel(const float* mse_r
     const int tid = threadIdx.x;
     const int nmax = max(max(B, rows_p), S);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int i = tid; i < nmax; i += 256) {
-        const float a0 = mse_row[max(0, min(i, B - 1))], a1 = piece_row[max(0, min(i, rows_p - 1))];
-        const float a2 = edge_row[max(0, min(i, S - 1))], a3 = klrow[max(0, min(i, B - 1))];
-        s0 += i < B ? a0 : 0.f; s1 += i < rows_p ? a1 : 0.f; s2 += i < S ? a2 : 0.f; s3 += i < B ? a3 : 0.f;
+    // eight strides per round, from clamped addresses: 32 loads in flight instead of one round trip per stride
+    // (a thread still adds its elements in index order, so the sums are what the one-by-one loop gave)
+    for (int i0 = tid; i0 < nmax; i0 += 8 * 256) {
+        float a0[8], a1[8], a2[8], a3[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            a0[u] = mse_row[max(0, min(i, B - 1))]; a1[u] = piece_row[max(0, min(i, rows_p - 1))];
+            a2[u] = edge_row[max(0, min(i, S - 1))]; a3[u] = klrow[max(0, min(i, B - 1))];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            s0 += i < B ? a0[u] : 0.f; s1 += i < rows_p ? a1[u] : 0.f; s2 += i < S ? a2[u] : 0.f; s3 += i < B ? a3[u] : 0.f;
+        }
     }
     sh[0][tid] = s0; sh[1][tid] = s1; sh[2][tid] = s2; sh[3][tid] = s3;
     __syncthreads();
