@@ -339,22 +339,21 @@ __global__ __launch_bounds__(256) void small_linear_fwd_shortk_kernel(const floa
     const int m = (int)(o / N), n = (int)(o - (long long)m * N);
     const float4* xr = reinterpret_cast<const float4*>(x + (long long)m * ldx);
     const float4* wr = reinterpret_cast<const float4*>(w + (long long)n * (K4 * 4));
-    float4 c[K4MAX];
+    float4 c[K4MAX], a[K4MAX];
 #pragma unroll
-    for (int k = 0; k < K4MAX; ++k) c[k] = wr[min(k, K4 - 1)];     // all in flight at once
+    for (int k = 0; k < K4MAX; ++k) { c[k] = wr[min(k, K4 - 1)]; a[k] = xr[min(k, K4 - 1)]; }     // all in flight at once
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < K4MAX; ++k) {
         if (k < K4) {
-            const float4 a = xr[k];
-            acc = fmaf(a.x, c[k].x, acc); acc = fmaf(a.y, c[k].y, acc); acc = fmaf(a.z, c[k].z, acc); acc = fmaf(a.w, c[k].w, acc);
+            acc = fmaf(a[k].x, c[k].x, acc); acc = fmaf(a[k].y, c[k].y, acc); acc = fmaf(a[k].z, c[k].z, acc); acc = fmaf(a[k].w, c[k].w, acc);
         }
     }
     if (on) y[(long long)m * ldy + n] = acc + (b ? b[n] : 0.f);
 }
 
 // dx[m][k] = sum_n dy[m][n] w[n][k]: one block per row m; thread (slice q, column k) sums a quarter of the n range
-// in order with eight rows of w in flight, the four slices are added in slice order through LDS.
+// in order with 32 rows of w (and the matching dy values) in flight, the four slices are added in slice order through LDS.
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
                                                               float* __restrict__ dx, int lddx, int M, int N, int K) {
     __shared__ float part[4][64];
@@ -363,12 +362,12 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
     const float* dr = dy + (long long)m * lddy;
     float acc = 0.f;
     if (k < K) {
-        for (int n = n0; n < n1; n += 8) {
-            float wv[8];
+        for (int n = n0; n < n1; n += 32) {
+            float wv[32], dv[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = w[(long long)min(n + u, n1 - 1) * K + k];
+            for (int u = 0; u < 32; ++u) { wv[u] = w[(long long)min(n + u, n1 - 1) * K + k]; dv[u] = dr[min(n + u, n1 - 1)]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = n + u < n1 ? fmaf(dr[n + u], wv[u], acc) : acc;
+            for (int u = 0; u < 32; ++u) acc = n + u < n1 ? fmaf(dv[u], wv[u], acc) : acc;
         }
     }
     part[q][kk] = acc;
