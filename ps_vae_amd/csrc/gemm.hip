@@ -170,9 +170,11 @@ __device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LA], const float
     return acc;
 }
 
-template <bool T, bool EDGE>
+// ONES: the operand may hold the ones column (the B operand of a weight-gradient product); off the edge path it
+// is patched in by four selects.
+template <bool T, bool EDGE, bool ONES>
 __device__ __forceinline__ void store_half(float (*s)[Pitch<T>::value], float4 v, const TileGeo& g, int r0, int q) {
-    store_quad<T>(s, EDGE ? apply_flags(v, quad_flags<T>(g, r0, q)) : v, q);
+    store_quad<T>(s, EDGE ? apply_flags(v, quad_flags<T>(g, r0, q)) : (ONES ? patch_ones<T>(v, g, q) : v), q);
 }
 
 // One K-step of the main loop as ONE instruction stream per wave.  With a few thousand rows there is at most one
@@ -207,12 +209,12 @@ __device__ __forceinline__ void kstep(const float (*cA)[Pitch<AT>::value], const
     PSVAE_READ(a1, b1, 1)
     PSVAE_SB();
     PSVAE_MFMA(a0[3], b0[3]);
-    store_half<AT, EDGE>(nA, sa.v0, ga, r_store, tid);
+    store_half<AT, EDGE, false>(nA, sa.v0, ga, r_store, tid);
     PSVAE_SB();
     PSVAE_MFMA(a1[0], b1[0]);
     PSVAE_SB();
     PSVAE_MFMA(a1[1], b1[1]);
-    store_half<AT, EDGE>(nA, sa.v1, ga, r_store, tid + 256);
+    store_half<AT, EDGE, false>(nA, sa.v1, ga, r_store, tid + 256);
     PSVAE_SB();
     PSVAE_MFMA(a1[2], b1[2]);
     PSVAE_READ(a0, b0, 2)
@@ -220,7 +222,7 @@ __device__ __forceinline__ void kstep(const float (*cA)[Pitch<AT>::value], const
     PSVAE_MFMA(a1[3], b1[3]);
     PSVAE_SB();
     PSVAE_MFMA(a0[0], b0[0]);
-    store_half<BT, EDGE>(nB, sb.v0, gb, r_store, tid);
+    store_half<BT, EDGE, true>(nB, sb.v0, gb, r_store, tid);
     PSVAE_SB();
     PSVAE_MFMA(a0[1], b0[1]);
     PSVAE_SB();
@@ -228,7 +230,7 @@ __device__ __forceinline__ void kstep(const float (*cA)[Pitch<AT>::value], const
     PSVAE_READ(a1, b1, 3)
     PSVAE_SB();
     PSVAE_MFMA(a0[3], b0[3]);
-    store_half<BT, EDGE>(nB, sb.v1, gb, r_store, tid + 256);
+    store_half<BT, EDGE, true>(nB, sb.v1, gb, r_store, tid + 256);
     PSVAE_SB();
     PSVAE_MFMA(a1[0], b1[0]);
     PSVAE_MFMA(a1[1], b1[1]);
@@ -296,10 +298,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
         __syncthreads();
         const int nq = nk >> 2, rem = nk & 3;
         if constexpr (PIPE) {
-            const bool ones_tile = BT && p.ones_col >= n0 && p.ones_col < n0 + BN;     // uniform
             for (int q = 0; q < nq; ++q) {
                 const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
-                if (!ones_tile && r4 + BK <= rend) {
+                if (r4 + BK <= rend) {
                     kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
                     kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
                     kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
@@ -435,15 +436,19 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
     }
 }
 
-// Reduction split: aim for ~2 workgroups per CU (PSVAE_SPLIT_TARGET overrides the 512 target) (occupancy hides the load latency of
-// these short K loops) while keeping at least 4 K-steps per workgroup.
+// Reduction split: a launch of few tiles is split along the reduction range into at most 384 workgroups - one to
+// two per CU, all resident at once, each with at least 4 K-steps; these launches run beside other streams' work in
+// the training step, where 512 cost the step 1.3 %, 256 0.6 % and rounding the slab count up instead of down
+// 1 %.  Reductions over 32 k rows or more (bulk weight gradients, a launch that has the GPU to itself for
+// hundreds of microseconds) get 512: 88 instead of 72 TFLOP/s at 95 k rows.  PSVAE_SPLIT_TARGET overrides both.
 struct Plan { int splits, rchunk; };
 Plan plan_splits(int M, int N, int R, int nseg) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nseg;
     Plan pl{1, (int)round_up(R > 0 ? R : 1, BK)};
     if (tiles >= 200 || R <= 4 * BK) return pl;
-    static const int target = [] { const char* e = getenv("PSVAE_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
-    int want = (int)(target / tiles);      // rounded down: 512 workgroups or fewer fit the GPU two per CU at once
+    static const int forced = [] { const char* e = getenv("PSVAE_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
+    const int target = forced > 0 ? forced : (R >= 32768 ? 512 : 384);
+    int want = (int)(target / tiles);      // rounded down
     int maxs = R / (4 * BK);
     if (want > maxs) want = maxs;
     if (want <= 1) return pl;
@@ -510,9 +515,8 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
             else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, true, false>), grid, dim3(256), 0, s, p);   \
             else hipLaunchKernelGGL((gemm_f32_kernel<AT_, BT_, false, false>), grid, dim3(256), 0, s, p);           \
         } while (0)
-        // the interleaved loop pays where a CU holds few workgroups and the operands are not both transposed
-        // (the weight-gradient products run long reductions over many co-resident workgroups)
-        const bool pipe = !(d.a_t && d.b_t) && (long long)grid.x * grid.y * grid.z <= 1024;
+        // the interleaved loop pays where a CU holds few workgroups (split reductions are planned for at most 512)
+        const bool pipe = (long long)grid.x * grid.y * grid.z <= 1024;
         if (!d.a_t && !d.b_t) PSVAE_GEMM_LAUNCH(false, false);
         else if (!d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(false, true);
         else if (d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(true, true);
