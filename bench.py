@@ -208,6 +208,12 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' rehearses the multi-rank "
                     "path on a box with fewer GPUs than ranks (ranks then share devices)")
     args = ap.parse_args()
+    # The result line is the ONLY thing this program writes to its standard output: libraries that chat on file
+    # descriptor 1 (RCCL prints a five-line version banner there when its first communicator is created) are sent
+    # to standard error for the whole run, and the JSON line goes to a private copy of the original descriptor.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     if os.environ.get('PSVAE_BENCH_WATCHDOG'):     # seconds; on expiry every thread's stack goes to stderr and the run ends
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['PSVAE_BENCH_WATCHDOG']), exit=True)
@@ -389,7 +395,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         qm9, _ = make_batches(tok, args.vocab, 'qm9', 32, 1, seed=7)
         out['cpu_baseline'] = cpu_baseline(cpu_batches[0], qm9[0], args.vocab)
-    print(json.dumps(out))
+    result_out.write(json.dumps(out) + '\n')
+    result_out.flush()
 
 
 if __name__ == '__main__':
