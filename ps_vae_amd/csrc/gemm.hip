@@ -172,6 +172,23 @@ __device__ __forceinline__ floatx16 tile_mfma(const float (*sa)[LA], const float
 
 // ONES: the operand may hold the ones column (the B operand of a weight-gradient product); off the edge path it
 // is patched in by four selects.
+// The first half of a K-step only (k = 0 .. 15): for a last K-step whose valid reduction range ends there.
+template <int LA, int LB>
+__device__ __forceinline__ floatx16 tile_mfma_half(const float (*sa)[LA], const float (*sb)[LB], int arow, int brow,
+                                                   int kh, floatx16 acc) {
+    float a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a0[u] = sa[u * 2 + kh][arow]; b0[u] = sb[u * 2 + kh][brow]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a1[u] = sa[8 + u * 2 + kh][arow]; b1[u] = sb[8 + u * 2 + kh][brow]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+    return acc;
+}
+
 template <bool T, bool EDGE, bool ONES>
 __device__ __forceinline__ void store_half(float (*s)[Pitch<T>::value], float4 v, const TileGeo& g, int r0, int q) {
     store_quad<T>(s, EDGE ? apply_flags(v, quad_flags<T>(g, r0, q)) : (ONES ? patch_ones<T>(v, g, q) : v), q);
@@ -342,19 +359,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
             }
         }
         // buffer 0 holds tile 4 nq; stages 0 and 1 hold the next two
+        // (a last K-step that holds at most 16 valid reduction indices runs half the MFMAs; uniform branches)
         const int rt = rbeg + 4 * nq * BK;
-        if (rem >= 1) acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
+        // (only in the interleaved-loop kernel: in the plain-loop kernel the extra branches cost the large
+        //  launches 8 % through a worse register assignment)
+        const bool short_last = PIPE && rend - (rbeg + (nk - 1) * BK) <= BK / 2;
+        if (rem >= 1) acc = (rem == 1 && short_last) ? tile_mfma_half(sA[0], sB[0], arow, brow, kh, acc) : tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
         if (rem >= 2) {
             store_stage<AT>(sA[1], a0, ga, rt + BK, tid);
             store_stage<BT>(sB[1], b0, gb, rt + BK, tid);
             __syncthreads();
-            acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
+            acc = (rem == 2 && short_last) ? tile_mfma_half(sA[1], sB[1], arow, brow, kh, acc) : tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
         }
         if (rem >= 3) {
             store_stage<AT>(sA[0], a1, ga, rt + 2 * BK, tid);
             store_stage<BT>(sB[0], b1, gb, rt + 2 * BK, tid);
             __syncthreads();
-            acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
+            acc = short_last ? tile_mfma_half(sA[0], sB[0], arow, brow, kh, acc) : tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
         }
     }
 
