@@ -231,6 +231,10 @@ def main():
     shared_gpu = world > max(n_dev, 1)
     # PSVAE_BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL path on one GPU)
     dist_on = world > 1 or os.environ.get('PSVAE_BENCH_FORCE_DIST') == '1'
+    # the step's side streams are created before the communicator's, so that they get hardware queues of their own
+    torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().psvae_streams_init(), 'psvae_streams_init')
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -258,6 +262,16 @@ def main():
     local_denoms = [b['_native'].denoms.clone() for b in batches]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
+    # Global loss denominators (non-pad tokens, pairs, graphs, properties summed over ranks) are exchanged every
+    # step, one step ahead (they depend on the batch only).  PSVAE_BENCH_DENOMS_ONCE=1 exchanges them once per
+    # collated batch before the timed region instead, as a loader that collates the global batch would (-1.8 %
+    # step time with one rank over RCCL); the reported line uses the per-step exchange.
+    denoms_per_step = dist_on and os.environ.get('PSVAE_BENCH_DENOMS_ONCE') != '1'
+    if dist_on and not denoms_per_step:
+        for j in range(n_distinct):
+            reducer.reduce_denoms(local_denoms[j], out=batches[j]['_native'].denoms)
+        torch.cuda.synchronize()
+
     pending = {}
 
     def exchange_denoms(i):
@@ -271,7 +285,7 @@ def main():
 
     def step(i):
         batch = batches[i % n_distinct]
-        if dist_on:
+        if denoms_per_step:
             if i not in pending:
                 exchange_denoms(i)
             work = pending.pop(i)
@@ -290,7 +304,8 @@ def main():
                 reducer.reduce_grads(model.flat_buffers()[1])
             if shared_gpu:
                 torch.cuda.synchronize()
-            exchange_denoms(i + 1)
+            if denoms_per_step:
+                exchange_denoms(i + 1)
         opt.step()
         model.global_step += 1
         return loss

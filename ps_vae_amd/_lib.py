@@ -108,6 +108,7 @@ def lib():
     L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp]
     L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp]
     L.psvae_step_backward_signal.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp, vp, vp]
+    L.psvae_streams_init.argtypes = []
     L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
     L.psvae_sample_pieces_workspace_bytes.restype = sz
     L.psvae_sample_pieces_workspace_bytes.argtypes = [P(Dims), C.c_int]
@@ -162,7 +163,7 @@ def lib():
 
 EXPORTS = (
     'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward',
-    'psvae_step_backward', 'psvae_step_backward_signal', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
+    'psvae_step_backward', 'psvae_step_backward_signal', 'psvae_streams_init', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
     'psvae_score_links', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',

@@ -260,6 +260,18 @@ Lanes* get_lanes() {
     }
     return per_device[dev];
 }
+// Creates the calling device's lanes now instead of inside the first step call.  HIP deals a process's streams
+// onto a few hardware queues (four by default) in the order they are created, and two streams that share a
+// queue run one after the other: a process that also creates communicator or library streams should call this
+// first, while the lanes can still get queues of their own beside the caller's stream.
+extern "C" int psvae_streams_init(void) {
+    Lanes* L = get_lanes();
+    if (!L) return 0;       // lanes disabled (PSVAE_STREAMS=0) or unavailable: every call stays on the caller's stream
+    if (hipEventRecord(L->ev[0], L->s1) != hipSuccess || hipEventRecord(L->ev[1], L->s2) != hipSuccess ||
+        hipStreamSynchronize(L->s1) != hipSuccess || hipStreamSynchronize(L->s2) != hipSuccess)
+        return (int)hipGetLastError();
+    return 0;
+}
 // `to` waits for everything enqueued so far on `from`
 int hand_over(hipStream_t from, hipStream_t to, hipEvent_t ev) {
     if (from == to) return 0;
