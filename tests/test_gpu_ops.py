@@ -101,7 +101,9 @@ def _random_graph(n, E, seed):
     return ei, et
 
 
-@pytest.mark.parametrize('n,E,H', [(500, 1100, 300), (64, 0, 20), (1, 3, 8), (2000, 9000, 512)])
+@pytest.mark.parametrize('n,E,H', [(500, 1100, 300), (64, 0, 20), (1, 3, 8), (2000, 9000, 512),
+                                   # outputs beyond 16 MB: the kernels write them with non-temporal stores
+                                   (16001, 40000, 300), (14000, 60000, 320), (24000, 0, 200), (70000, 90000, 64)])
 def test_gine_aggregate_forward_backward(n, E, H):
     from ps_vae_amd import ops
     ei, et = _random_graph(n, E, seed=n)
