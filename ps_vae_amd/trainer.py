@@ -82,42 +82,66 @@ def load_checkpoint(path, model, optimizer=None):
     return int(ckpt.get('epoch', 0))
 
 
-def validate(model, loader, device):
-    """Mean of `validation_step` over a loader (`ps_vae_model.py:90-96`)."""
-    tot = {'val_loss': 0.0, 'piece accu': 0.0, 'edge accu': 0.0}
-    n = 0
+def validate(model, loader, device, reducer=None):
+    """Mean of `validation_step` over a loader (`ps_vae_model.py:90-96`).  With a `reducer` every rank passes
+    its own shard of the validation set and all ranks get the mean over all shards' batches."""
+    keys = ('val_loss', 'piece accu', 'edge accu')
+    tot = torch.zeros(len(keys) + 1, dtype=torch.float64)
     with torch.no_grad():
         for batch in loader:
             out = model.validation_step(to_device(batch, device))
-            for k in tot:
-                tot[k] += float(out[k])
-            n += 1
-    return {k: v / max(n, 1) for k, v in tot.items()}
+            for i, k in enumerate(keys):
+                tot[i] += float(out[k])
+            tot[-1] += 1
+    if reducer is not None and reducer.active:
+        tot = tot.to(device)
+        reducer._all_reduce(tot)
+        tot = tot.cpu()
+    n = max(float(tot[-1]), 1.0)
+    return {k: float(tot[i]) / n for i, k in enumerate(keys)}
 
 
-def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3, device='cuda', log=None):
+def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3, device='cuda', log=None, reducer=None):
     """Epoch loop of `trainer.fit` as the reference configures it: Adam with lr / (epoch + 1), clip 10 (both in
     `configure_optimizers()`'s fused optimiser), validation after every epoch, best-`val_loss` checkpoint,
-    KL-aware early stopping.  Returns the per-epoch validation records."""
+    KL-aware early stopping.  Returns the per-epoch validation records.
+
+    Data-parallel (no reference counterpart; its Lightning 'dp' mode mis-splits the batch dict, `src/train.py:49-50`):
+    pass a `parallel.GradReducer` and give every rank loaders over its own shard of the graphs, with the same
+    number of batches on every rank.  Each step then divides the local loss sums by the global counts and sums
+    the flat gradient over ranks, which is the step of the undivided batch; validation records are means over
+    all ranks, so every rank takes the same early-stopping decision, and rank 0 alone writes the checkpoint."""
     opt = model.configure_optimizers()
     stopper = VAEEarlyStopping(finish_anneal_step(model.config), patience=patience)
     history, best = [], math.inf
+    dp = reducer is not None and reducer.active
+    writer = not dp or torch.distributed.get_rank(reducer.group) == 0
     for epoch in range(max_epochs):
         opt.set_epoch(epoch)
         for batch in train_loader:
+            batch = to_device(batch, device)
+            if dp:
+                if '_native' not in batch:
+                    raise ValueError('data-parallel fit needs batches from BPEMolDataset, PackedMolDataset '
+                                     'or DeviceLoader (their loss denominators are exchanged between ranks)')
+                denoms = batch['_native'].denoms
+                reducer.reduce_denoms(denoms.clone(), out=denoms)
             opt.zero_grad()
-            loss = model.training_step(to_device(batch, device))
+            loss = model.training_step(batch)
             loss.backward(model.unit_grad())
+            if dp:
+                reducer.reduce_grads(model.flat_buffers()[1])
             opt.step()
             model.global_step += 1
-        rec = validate(model, valid_loader, device)
+        rec = validate(model, valid_loader, device, reducer)
         rec.update(epoch=epoch, global_step=model.global_step)
         history.append(rec)
         if log:
             log(rec)
         if save_dir is not None and rec['val_loss'] < best:
             best = rec['val_loss']
-            save_checkpoint(os.path.join(save_dir, 'best.ckpt'), model, opt, epoch)
+            if writer:
+                save_checkpoint(os.path.join(save_dir, 'best.ckpt'), model, opt, epoch)
         if stopper.on_validation_end(rec['val_loss'], model.global_step):
             break
     return history
