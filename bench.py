@@ -231,10 +231,14 @@ def main():
     shared_gpu = world > max(n_dev, 1)
     # PSVAE_BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL path on one GPU)
     dist_on = world > 1 or os.environ.get('PSVAE_BENCH_FORCE_DIST') == '1'
-    # the step's side streams are created before the communicator's, so that they get hardware queues of their own
-    torch.zeros(1, device=dev)
-    torch.cuda.synchronize()
-    _lib.check(_lib.lib().psvae_streams_init(), 'psvae_streams_init')
+    # the step's side streams are created before the communicator's, and checked to run beside the current stream
+    def init_streams():
+        torch.zeros(1, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().psvae_streams_init(torch.cuda.current_stream().cuda_stream), 'psvae_streams_init')
+    late_streams = os.environ.get('PSVAE_BENCH_LATE_STREAMS') == '1'     # test switch: communicator first
+    if not late_streams:
+        init_streams()
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -246,6 +250,8 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
+    if late_streams:
+        init_streams()
     tok = Tokenizer.synthetic(args.vocab)
     torch.manual_seed(2021)
     model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)

@@ -164,12 +164,15 @@ int psvae_step_backward_signal(const psvae_dims* dims, const psvae_params* param
                                void* workspace, size_t workspace_bytes, const float* loss_weights,
                                const float* loss_grads, const psvae_params* grads, void* stream,
                                void* early_event_1, void* early_event_2);
-/* Creates the current device's two internal side streams now rather than inside the first step call (no
- * counterpart in the reference).  HIP deals the streams of a process onto a small number of hardware queues in
- * creation order and streams that share a queue serialise, so a process that also creates communicator (RCCL)
- * or other library streams calls this first, right after selecting the device; otherwise optional.  Returns 0
- * also when the side streams are disabled (PSVAE_STREAMS=0). */
-int psvae_streams_init(void);
+/* Creates the current device's two internal side streams now rather than inside the first step call, and checks
+ * (with two 100 us probe kernels per pair, timed from the host) that they and `stream` -- the stream the step
+ * calls will be given, NULL for the default stream -- run side by side; a side stream that does not is replaced
+ * by a newly created one, up to eight times.  No counterpart in the reference.  HIP deals the streams of a process
+ * onto a small number of hardware queues in creation order and streams that share a queue serialise, so a process
+ * that also creates communicator (RCCL) or other library streams should call this once per device; otherwise
+ * optional (the first step call creates the side streams without the check).  Synchronises `stream`.  Returns 0
+ * also when the side streams are disabled (PSVAE_STREAMS=0) or already exist. */
+int psvae_streams_init(void* stream);
 /* Offsets (in floats) of named activations inside the workspace, for tests and
  * the module-level API.  Returns -1 for an unknown name. */
 int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_batch* batch_sizes, const char* name);

@@ -108,7 +108,7 @@ def lib():
     L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp]
     L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp]
     L.psvae_step_backward_signal.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp, vp, vp]
-    L.psvae_streams_init.argtypes = []
+    L.psvae_streams_init.argtypes = [vp]
     L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
     L.psvae_sample_pieces_workspace_bytes.restype = sz
     L.psvae_sample_pieces_workspace_bytes.argtypes = [P(Dims), C.c_int]

@@ -8,8 +8,11 @@
 // stacks run the same number of iterations, every per-layer launch handles the
 // encoder and the decoder-side encoder together (grid dimension = group).
 #include "psvae_internal.h"
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <chrono>
 #include <mutex>
 
 namespace {
@@ -234,41 +237,77 @@ int stacks_edge_grads(hipStream_t st, const Sz& s, const WS& w, const Stack* k, 
 // caller's stream, so from outside the call still behaves like work on that one stream.
 // Set PSVAE_STREAMS=0 to run everything on the caller's stream.
 struct Lanes { hipStream_t s1, s2; hipEvent_t ev[16]; };
-Lanes* get_lanes() {
-    static std::mutex mu;
-    static Lanes* per_device[64] = {};
-    static int disabled = -1;
-    std::lock_guard<std::mutex> lock(mu);
-    if (disabled < 0) { const char* e = getenv("PSVAE_STREAMS"); disabled = (e && e[0] == '0') ? 1 : 0; }
-    if (disabled) return nullptr;
+std::mutex lanes_mu;
+Lanes* lanes_per_device[64] = {};
+int lanes_disabled = -1;
+
+// PSVAE_LANE_PRIORITY=1: lane 1 (GRU, on the critical path) gets the highest stream priority and lane 2
+// (weight-gradient products nobody waits for until the end of the step) the lowest.  Worth ~2 % on a
+// GPU this process owns; off by default because with a second process on the same GPU the
+// low-priority lane was observed never to finish.
+bool create_lane(hipStream_t* s, bool first) {
+    int least = 0, greatest = 0;
+    const char* pe = getenv("PSVAE_LANE_PRIORITY");
+    if (pe && pe[0] == '1') (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, first ? greatest : least) == hipSuccess;
+}
+
+// One wave that keeps a compute unit busy for a fixed time (constant 100 MHz counter), for lanes_overlap().
+__global__ void lane_probe_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+// Do kernels on streams `a` and `b` run side by side?  HIP deals a process's streams onto a few hardware
+// queues and two streams that landed on the same queue take turns.  Two 100 us probes are launched, one on
+// each stream, and timed from the host: side by side they take little more than 100 us, in turn 200 us.
+bool lanes_overlap(hipStream_t a, hipStream_t b) {
+    double best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, a, 10000LL);
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, b, 10000LL);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best < 165.0;
+}
+
+Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
+    std::lock_guard<std::mutex> lock(lanes_mu);
+    if (lanes_disabled < 0) { const char* e = getenv("PSVAE_STREAMS"); lanes_disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (lanes_disabled) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!per_device[dev]) {
+    if (!lanes_per_device[dev]) {
         Lanes* l = new Lanes();
-        // PSVAE_LANE_PRIORITY=1: lane 1 (GRU, on the critical path) gets the highest stream priority and lane 2
-        // (weight-gradient products nobody waits for until the end of the step) the lowest.  Worth ~2 % on a
-        // GPU this process owns; off by default because with a second process on the same GPU the
-        // low-priority lane was observed never to finish.
-        int least = 0, greatest = 0;
-        const char* pe = getenv("PSVAE_LANE_PRIORITY");
-        if (pe && pe[0] == '1') (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        bool ok = hipStreamCreateWithPriority(&l->s1, hipStreamNonBlocking, greatest) == hipSuccess &&
-                  hipStreamCreateWithPriority(&l->s2, hipStreamNonBlocking, least) == hipSuccess;
+        bool ok = create_lane(&l->s1, true) && create_lane(&l->s2, false);
+        // With `probe`, a lane that shares its hardware queue with the caller's stream or with the other lane is
+        // replaced by a newly created stream (which gets the next queue) until all three run side by side; the
+        // rejected streams are kept until the search is over so that their queues stay taken.
+        hipStream_t rejected[16]; int nrej = 0;
+        for (int attempt = 0; ok && probe && attempt < 8; ++attempt) {
+            if (!lanes_overlap(caller, l->s1)) { rejected[nrej++] = l->s1; ok = create_lane(&l->s1, true); continue; }
+            if (!lanes_overlap(caller, l->s2) || !lanes_overlap(l->s1, l->s2)) { rejected[nrej++] = l->s2; ok = create_lane(&l->s2, false); continue; }
+            break;
+        }
+        for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+        if (probe && getenv("PSVAE_STREAMS_DEBUG")) fprintf(stderr, "psvae_streams_init: device %d, %d side stream(s) replaced\n", dev, nrej);
         for (int i = 0; ok && i < 16; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { delete l; disabled = 1; return nullptr; }
-        per_device[dev] = l;
+        if (!ok) { delete l; lanes_disabled = 1; return nullptr; }
+        lanes_per_device[dev] = l;
     }
-    return per_device[dev];
+    return lanes_per_device[dev];
 }
-// Creates the calling device's lanes now instead of inside the first step call.  HIP deals a process's streams
-// onto a few hardware queues (four by default) in the order they are created, and two streams that share a
-// queue run one after the other: a process that also creates communicator or library streams should call this
-// first, while the lanes can still get queues of their own beside the caller's stream.
-extern "C" int psvae_streams_init(void) {
-    Lanes* L = get_lanes();
+// Creates the calling device's lanes now instead of inside the first step call, and makes sure that they and
+// `stream` (the stream the step calls will be given) sit on different hardware queues.  HIP deals a process's
+// streams onto a few hardware queues (four by default) in the order they are created, and two streams that
+// share a queue run one after the other; which queue a stream gets depends on every other stream the process
+// (communicator, libraries) has created before.
+extern "C" int psvae_streams_init(void* stream) {
+    Lanes* L = get_lanes(true, (hipStream_t)stream);
     if (!L) return 0;       // lanes disabled (PSVAE_STREAMS=0) or unavailable: every call stays on the caller's stream
-    if (hipEventRecord(L->ev[0], L->s1) != hipSuccess || hipEventRecord(L->ev[1], L->s2) != hipSuccess ||
-        hipStreamSynchronize(L->s1) != hipSuccess || hipStreamSynchronize(L->s2) != hipSuccess)
+    if (hipStreamSynchronize(L->s1) != hipSuccess || hipStreamSynchronize(L->s2) != hipSuccess)
         return (int)hipGetLastError();
     return 0;
 }

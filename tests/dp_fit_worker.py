@@ -34,7 +34,7 @@ def main(out_path):
     torch.cuda.set_device(0)
     torch.zeros(1, device='cuda')
     torch.cuda.synchronize()
-    _lib.check(_lib.lib().psvae_streams_init(), 'psvae_streams_init')
+    _lib.check(_lib.lib().psvae_streams_init(torch.cuda.current_stream().cuda_stream), 'psvae_streams_init')
     dist.init_process_group('gloo')
     tok = Tokenizer.synthetic(V)
     train = get_dataloader(shard(synth.make_molecules(1, 'qm9', V, 2 * PER_RANK * STEPS), rank), tok, batch_size=PER_RANK,

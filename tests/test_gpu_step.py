@@ -182,8 +182,9 @@ def test_gradient_accumulation_and_determinism():
     g1, g2 = grads(), grads()
     assert torch.equal(g1, g2), 'two runs of the same step must be bitwise identical'
     from ps_vae_amd import _lib
-    assert _lib.lib().psvae_streams_init() == 0      # idempotent once the side streams exist; results unchanged
-    assert _lib.lib().psvae_streams_init() == 0
+    st = torch.cuda.current_stream().cuda_stream
+    assert _lib.lib().psvae_streams_init(st) == 0      # idempotent once the side streams exist; results unchanged
+    assert _lib.lib().psvae_streams_init(None) == 0
     assert torch.equal(grads(), g1)
     pred, (rec, _, _, kl) = model(batch, eps=eps)      # second backward without zero_grad accumulates
     model.weighted_loss(pred, rec, kl).backward()
