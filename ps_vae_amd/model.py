@@ -155,6 +155,11 @@ class PSVAEModel(nn.Module):
         order = FLAT_ORDER + UNTRAINED
         assert sorted(order) == sorted(named.keys()), 'parameter set differs from the reference state-dict'
         dev = named[order[0]].device
+        if dev.type == 'cuda':
+            # the step's side streams are created (and checked to run beside the current stream) before anything
+            # else this process may create later, e.g. a communicator's streams
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().psvae_streams_init(torch.cuda.current_stream(dev).cuda_stream), 'psvae_streams_init')
         offs, off = {}, 0
         for k in order:
             if k == UNTRAINED[0]:
