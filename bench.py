@@ -269,11 +269,19 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     # Global loss denominators (non-pad tokens, pairs, graphs, properties summed over ranks) are exchanged every
-    # step, one step ahead (they depend on the batch only).  PSVAE_BENCH_DENOMS_ONCE=1 exchanges them once per
-    # collated batch before the timed region instead, as a loader that collates the global batch would (-1.8 %
-    # step time with one rank over RCCL); the reported line uses the per-step exchange.
-    denoms_per_step = dist_on and os.environ.get('PSVAE_BENCH_DENOMS_ONCE') != '1'
-    if dist_on and not denoms_per_step:
+    # step, one step ahead (they depend on the batch only).  PSVAE_BENCH_DENOMS selects how: "ride" (default) puts
+    # the next batch's four local counts behind the gradients, so that the gradient all-reduce sums them too;
+    # "async" uses a collective of their own on the communicator's stream; "once" exchanges them once per collated
+    # batch before the timed region, as a loader that collates the global batch would.
+    denoms_mode = os.environ.get('PSVAE_BENCH_DENOMS', 'ride') if dist_on else 'none'
+    if overlap is not None and denoms_mode == 'ride':
+        denoms_mode = 'async'       # the overlapped reducer sends the gradients as two messages of its own
+    denoms_per_step = denoms_mode == 'async'
+    if denoms_mode == 'ride':
+        message, tail = model.grad_message()
+        message_reducer = GradReducer([0, message.numel()], always=dist_on)
+        delivered = {}              # step index -> its batch holds the global denominators
+    if denoms_mode == 'once':
         for j in range(n_distinct):
             reducer.reduce_denoms(local_denoms[j], out=batches[j]['_native'].denoms)
         torch.cuda.synchronize()
@@ -297,6 +305,8 @@ def main():
             work = pending.pop(i)
             if work is not None:
                 work.wait()
+        if denoms_mode == 'ride' and not delivered.pop(i, False):     # first step only: nothing has carried them yet
+            reducer.reduce_denoms(local_denoms[i % n_distinct], out=batch['_native'].denoms)
         eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
         opt.zero_grad()
         loss = model.training_step(batch, eps=eps)
@@ -306,6 +316,12 @@ def main():
                 torch.cuda.synchronize()
             if overlap is not None:
                 overlap.reduce()
+            elif denoms_mode == 'ride':
+                nxt = (i + 1) % n_distinct
+                tail.copy_(local_denoms[nxt])
+                message_reducer.reduce_grads(message)
+                batches[nxt]['_native'].denoms.copy_(tail)
+                delivered[i + 1] = True
             else:
                 reducer.reduce_grads(model.flat_buffers()[1])
             if shared_gpu:

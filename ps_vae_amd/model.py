@@ -167,7 +167,9 @@ class PSVAEModel(nn.Module):
             offs[k] = off
             off += (named[k].numel() + 3) // 4 * 4
         flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        gflat = torch.zeros(self._n_trained, dtype=torch.float32, device=dev)
+        # four spare floats behind the gradients: a data-parallel caller can let a few numbers (the next batch's
+        # loss denominators) ride on the gradient message (`grad_message`)
+        gflat = torch.zeros(self._n_trained + 4, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for k in order:
                 p = named[k]
@@ -209,7 +211,13 @@ class PSVAEModel(nn.Module):
     def flat_buffers(self):
         """(parameters, gradients) as flat fp32 tensors over the trained range."""
         self._sync_flat()
-        return self._flat[:self._n_trained], self._gflat
+        return self._flat[:self._n_trained], self._gflat[:self._n_trained]
+
+    def grad_message(self):
+        """(message, tail): the flat gradient buffer with its four spare floats, and a view of those four.  All-reducing
+        `message` instead of the gradients alone carries four caller-chosen numbers along in the same collective."""
+        self._sync_flat()
+        return self._gflat, self._gflat[self._n_trained:]
 
     def early_gradient_events(self):
         """Two CUDA events that every following backward records as soon as the gradients of the flat range
