@@ -8,8 +8,12 @@ One "step" = one optimiser step over one batch of 128 graphs per GPU (vocab 300,
 hidden 300: the configuration the metric is quoted on).  Batches are collated on
 the host beforehand and resident in HBM when the timed region starts; parameters
 are randomly initialised (no checkpoints exist offline).  With N > 1 every rank
-processes its own 128 graphs (weak scaling) and the flat gradient buffer is
-all-reduced over RCCL each step.  Rank 0 prints ONE JSON line.
+processes its own 128 graphs (weak scaling; `--scaling strong --global-batch G`
+splits G graphs over the ranks instead) and the flat gradient buffer is
+all-reduced over RCCL each step, in three messages overlapped with backward.
+Started without a launcher (`WORLD_SIZE` unset) the program starts the N rank
+processes itself.  Rank 0 prints ONE JSON line; its "strong_scaling" object is a
+second, shorter measurement of vocab 500 / global batch 1024 split over the GPUs.
 """
 import argparse
 import json
@@ -26,7 +30,7 @@ sys.path.insert(0, ROOT)
 from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config, synth  # noqa: E402
 from ps_vae_amd import _lib  # noqa: E402
 from ps_vae_amd.data import BPEMolDataset, PackedMolDataset, to_device  # noqa: E402
-from ps_vae_amd.parallel import GradReducer, OverlappedReducer  # noqa: E402
+from ps_vae_amd.parallel import GradReducer, OverlappedReducer, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -182,10 +186,10 @@ def bulk_message_passing(dev, graphs=4096, H=300, iters=40):
 PMC_FILE = 'profiles/r01_pmc_traffic.json'
 
 
-def pmc_traffic(kernel_class, args):
+def pmc_traffic(kernel_class, args, per_gpu):
     """HBM-side bytes per launch of a kernel class, measured beforehand with rocprofv3 PMC passes of this
     same command (tools/pmc_traffic.py wrote the summary); None when no measurement of this workload exists."""
-    if (args.shape, args.vocab, args.batch_size) != ('zinc', 300, 128):
+    if (args.shape, args.vocab, per_gpu) != ('zinc', 300, 128):
         return None
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
@@ -194,20 +198,192 @@ def pmc_traffic(kernel_class, args):
         return None
 
 
+def make_sharded_batches(tok, vocab, shape, global_batch, count, seed, rank, world):
+    """`count` global batches of `global_batch` synthetic graphs each; this rank's contiguous shard
+    (`parallel.shard_range`) of every one, collated.  All ranks walk through all shards in order, so Python's
+    `random` stream (the negative-pair draws of stage 3) is consumed exactly as one process collating the shards one
+    after the other would consume it: the union of the ranks' batches does not depend on the number of ranks.
+    Each batch remembers where its shard starts inside the global batch (`graph_base` keys the epsilon draw)."""
+    out, mine = [], []
+    for i in range(count):
+        mols = synth.make_molecules(seed * 1000 + i, shape, vocab, global_batch)
+        random.seed(seed * 7919 + i)
+        for q in range(world):
+            lo, hi = shard_range(global_batch, q, world)
+            step2 = [BPEMolDataset.process_step2(m, tok, lists=False) for m in mols[lo:hi]]
+            b = BPEMolDataset.process_step3(step2, tok)
+            if q == rank:
+                b['_native'].graph_base = lo
+                out.append(b)
+                mine.append(mols[lo:hi])
+    return out, mine
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started without a launcher: this process (which never touches a GPU) starts the N rank
+    processes itself, one per GPU, and passes rank 0's result line through on its own standard output."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    code = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and code == 0:
+                    code = rc
+                    for other in pending:       # one rank failed: the others would wait for it in a collective
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return code
+
+
+class Leg:
+    """One measured configuration: a model, its optimiser, this rank's resident batches and the data-parallel
+    exchange.  `step(i)` is one optimiser step (forward, backward, gradient all-reduce, clip + Adam)."""
+
+    def __init__(self, args, dev, rank, world, dist_on, shared_gpu, vocab, per_gpu, global_batch, shape, n_distinct=8):
+        self.args, self.dev, self.rank, self.world, self.dist_on, self.shared_gpu = args, dev, rank, world, dist_on, shared_gpu
+        self.vocab, self.per_gpu, self.global_batch, self.n_distinct = vocab, per_gpu, global_batch, n_distinct
+        tok = self.tok = Tokenizer.synthetic(vocab)
+        torch.manual_seed(2021)
+        self.model = model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)
+        self.opt = model.configure_optimizers()
+        t0 = time.perf_counter()
+        self.cpu_batches, self.mols = make_sharded_batches(tok, vocab, shape, global_batch, n_distinct, 2021, rank, world)
+        self.collate_s = (time.perf_counter() - t0) / (n_distinct * world)      # every rank collated every shard
+        self.batches = [to_device(b, dev) for b in self.cpu_batches]
+        model.flat_buffers()
+        # Global loss denominators (non-pad tokens, pairs, graphs, properties summed over ranks) depend on the batch
+        # only.  PSVAE_BENCH_DENOMS selects how they are exchanged: "ride" (default) puts the NEXT batch's four local
+        # counts behind the gradients, so that the last gradient message sums them too (no collective of their own);
+        # "once" exchanges them once per collated batch before the timed region, as a loader that collates the
+        # global batch would.
+        self.denoms_mode = os.environ.get('PSVAE_BENCH_DENOMS', 'ride') if dist_on else 'none'
+        tail = 4 if self.denoms_mode == 'ride' else 0
+        self.message, self.tail = model.grad_message()
+        if not dist_on:
+            self.reducer = None
+        elif os.environ.get('PSVAE_DP_OVERLAP', '1') != '0':
+            # three gradient messages in the order backward finishes them, the first two overlapped with it
+            self.reducer = OverlappedReducer(model, always=True, tail=tail)
+        else:
+            self.reducer = GradReducer([0, model._n_trained + tail], always=True)     # one message after backward
+        self.delivered = {}
+        if self.denoms_mode == 'once':
+            for b in self.batches:
+                nb = b['_native']
+                self.reducer.reduce_denoms(nb.local_denoms, out=nb.denoms)
+            torch.cuda.synchronize()
+        self.unit = model.unit_grad()       # loss.backward(unit): no fill / copy launches for the implicit gradient of 1
+
+    def step(self, i):
+        model, n = self.model, self.n_distinct
+        batch = self.batches[i % n]
+        nb = batch['_native']
+        if self.denoms_mode == 'ride' and not self.delivered.pop(i, False):     # first step only: nothing has carried them yet
+            self.reducer.reduce_denoms(nb.local_denoms, out=nb.denoms)
+        self.opt.zero_grad()
+        loss = model.training_step(batch)       # epsilon: counter-based draw keyed by (seed, step, global graph index)
+        loss.backward(self.unit)
+        if self.dist_on:
+            if self.shared_gpu:
+                torch.cuda.synchronize()
+            if self.denoms_mode == 'ride':
+                nxt = self.batches[(i + 1) % n]['_native']
+                self.tail.copy_(nxt.local_denoms)
+            if isinstance(self.reducer, OverlappedReducer):
+                self.reducer.reduce()
+            else:
+                self.reducer.reduce_grads(self.message)
+            if self.denoms_mode == 'ride':
+                nxt.denoms.copy_(self.tail)
+                self.delivered[i + 1] = True
+            if self.shared_gpu:
+                torch.cuda.synchronize()
+        self.opt.step()
+        model.global_step += 1
+        return loss
+
+    def fence(self):
+        if self.dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` timed ones between two fences (barrier + device
+        synchronise); the time is the maximum over ranks."""
+        for i in range(warmup):
+            self.step(i)
+        self.fence()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            loss = self.step(warmup + i)
+            marks[i + 1].record()       # per-step spread (median, p10, p90); the headline stays total time / steps
+        host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        final = loss.detach().double().reshape(1).clone()
+        if self.dist_on:
+            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t)
+            # a rank's loss is its share of the global batch's loss (local sums over global counts)
+            torch.distributed.all_reduce(final, op=torch.distributed.ReduceOp.SUM)
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        spread = {'median': per_step[len(per_step) // 2], 'p10': per_step[int(0.1 * (len(per_step) - 1))],
+                  'p90': per_step[int(0.9 * (len(per_step) - 1))]}
+        if self.model.recurrence_gave_up():
+            raise SystemExit('the multi-CU GRU recurrence timed out during the run: results are invalid')
+        self.next_step = warmup + steps
+        return {'elapsed': elapsed, 'ms_per_step': elapsed / steps * 1e3, 'value': self.global_batch * steps / elapsed,
+                'step_ms': spread, 'host_enqueue_ms_per_step': host_enqueue_s / steps * 1e3, 'final_loss': float(final)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--batch-size', type=int, default=128, help='graphs per GPU')
+    ap.add_argument('--batch-size', type=int, default=128, help='graphs per GPU (weak scaling)')
     ap.add_argument('--vocab', type=int, default=300)
     ap.add_argument('--shape', default='zinc')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: --batch-size graphs per GPU; strong: --global-batch graphs split over the GPUs')
+    ap.add_argument('--global-batch', type=int, default=1024, help='graphs per step over all GPUs (strong scaling)')
+    ap.add_argument('--config3-steps', type=int, default=40,
+                    help='timed steps of the extra leg "vocab 500, global batch 1024 split over the GPUs" reported under '
+                         '"strong_scaling" (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bulk', action='store_true', help='skip the aggregation kernels at the bulk-encoding size')
     ap.add_argument('--profile-steps', type=int, default=10)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' rehearses the multi-rank "
                     "path on a box with fewer GPUs than ranks (ranks then share devices)")
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: start the ranks here, before anything in this process touches a GPU
+        if args.backend == 'nccl' and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'{args.gpus} ranks over RCCL need {args.gpus} GPUs, this node shows {torch.cuda.device_count()} '
+                             "(--backend gloo rehearses the multi-rank path on fewer)")
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     # The result line is the ONLY thing this program writes to its standard output: libraries that chat on file
     # descriptor 1 (RCCL prints a five-line version banner there when its first communicator is created) are sent
     # to standard error for the whole run, and the JSON line goes to a private copy of the original descriptor.
@@ -221,14 +397,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} ranks')
     n_dev = torch.cuda.device_count()
     if world > 1 and args.backend == 'nccl' and n_dev < world:
         raise SystemExit(f'{world} ranks over RCCL need {world} GPUs, this node shows {n_dev}')
+    # Rehearsal only (gloo, fewer GPUs than ranks): processes that share a GPU must not block on a collective
+    # while their own queue still holds work that waits for it, or the other process may never get the GPU; and the
+    # multi-CU recurrence (workgroups that wait for each other) is replaced by the single-CU kernels there.
+    shared_gpu = world > max(n_dev, 1)
+    if shared_gpu:
+        os.environ.setdefault('PSVAE_GRU_MULTI_CU', '0')
     dev = torch.device('cuda', local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
-    # Rehearsal only (gloo, fewer GPUs than ranks): processes that share a GPU must not block on a collective
-    # while their own queue still holds work that waits for it, or the other process may never get the GPU.
-    shared_gpu = world > max(n_dev, 1)
     # PSVAE_BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL path on one GPU)
     dist_on = world > 1 or os.environ.get('PSVAE_BENCH_FORCE_DIST') == '1'
     # the step's side streams are created before the communicator's, and checked to run beside the current stream
@@ -249,122 +430,23 @@ def main():
             dist.init_process_group(backend='nccl', device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
-
     if late_streams:
         init_streams()
-    tok = Tokenizer.synthetic(args.vocab)
-    torch.manual_seed(2021)
-    model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)
-    opt = model.configure_optimizers()
-    n_distinct = 8
-    host_times = {}
-    cpu_batches, collate_s = make_batches(tok, args.vocab, args.shape, args.batch_size, n_distinct, seed=2021 + rank,
-                                          host_times=host_times)
-    batches = [to_device(b, dev) for b in cpu_batches]
-    model.flat_buffers()
-    reducer = GradReducer([0, model._n_trained], always=dist_on)     # one collective for the whole gradient (7.6 MB)
-    # PSVAE_BENCH_OVERLAP=1: two gradient messages, the first one overlapped with the rest of backward
-    overlap = OverlappedReducer(model, always=dist_on) if dist_on and os.environ.get('PSVAE_BENCH_OVERLAP') == '1' else None
-    local_denoms = [b['_native'].denoms.clone() for b in batches]
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
-    # Global loss denominators (non-pad tokens, pairs, graphs, properties summed over ranks) are exchanged every
-    # step, one step ahead (they depend on the batch only).  PSVAE_BENCH_DENOMS selects how: "ride" (default) puts
-    # the next batch's four local counts behind the gradients, so that the gradient all-reduce sums them too;
-    # "async" uses a collective of their own on the communicator's stream; "once" exchanges them once per collated
-    # batch before the timed region, as a loader that collates the global batch would.
-    denoms_mode = os.environ.get('PSVAE_BENCH_DENOMS', 'ride') if dist_on else 'none'
-    if overlap is not None and denoms_mode == 'ride':
-        denoms_mode = 'async'       # the overlapped reducer sends the gradients as two messages of its own
-    denoms_per_step = denoms_mode == 'async'
-    if denoms_mode == 'ride':
-        message, tail = model.grad_message()
-        message_reducer = GradReducer([0, message.numel()], always=dist_on)
-        delivered = {}              # step index -> its batch holds the global denominators
-    if denoms_mode == 'once':
-        for j in range(n_distinct):
-            reducer.reduce_denoms(local_denoms[j], out=batches[j]['_native'].denoms)
-        torch.cuda.synchronize()
-
-    pending = {}
-
-    def exchange_denoms(i):
-        # global loss denominators of batch i: needs only the batch, so it is issued one step ahead
-        if shared_gpu:
-            torch.cuda.synchronize()
-        j = i % n_distinct
-        pending[i] = reducer.reduce_denoms(local_denoms[j], out=batches[j]['_native'].denoms, async_op=True)[1]
-
-    unit = model.unit_grad()       # loss.backward(unit): no fill / copy launches for the implicit gradient of 1
-
-    def step(i):
-        batch = batches[i % n_distinct]
-        if denoms_per_step:
-            if i not in pending:
-                exchange_denoms(i)
-            work = pending.pop(i)
-            if work is not None:
-                work.wait()
-        if denoms_mode == 'ride' and not delivered.pop(i, False):     # first step only: nothing has carried them yet
-            reducer.reduce_denoms(local_denoms[i % n_distinct], out=batch['_native'].denoms)
-        eps = torch.randn(args.batch_size, 56, device=dev, generator=gen)
-        opt.zero_grad()
-        loss = model.training_step(batch, eps=eps)
-        loss.backward(unit)
-        if dist_on:
-            if shared_gpu:
-                torch.cuda.synchronize()
-            if overlap is not None:
-                overlap.reduce()
-            elif denoms_mode == 'ride':
-                nxt = (i + 1) % n_distinct
-                tail.copy_(local_denoms[nxt])
-                message_reducer.reduce_grads(message)
-                batches[nxt]['_native'].denoms.copy_(tail)
-                delivered[i + 1] = True
-            else:
-                reducer.reduce_grads(model.flat_buffers()[1])
-            if shared_gpu:
-                torch.cuda.synchronize()
-            if denoms_per_step:
-                exchange_denoms(i + 1)
-        opt.step()
-        model.global_step += 1
-        return loss
-
-    def fence():
-        if dist_on:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-        marks[i + 1].record()       # per-step spread (median, p10, p90); the headline stays total time / steps
-    host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
-    final_loss = float(loss.detach())
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    spread = {'median': per_step[len(per_step) // 2], 'p10': per_step[int(0.1 * (len(per_step) - 1))],
-              'p90': per_step[int(0.9 * (len(per_step) - 1))]}
-    if model.recurrence_gave_up():
-        raise SystemExit('the multi-CU GRU recurrence timed out during the run: results are invalid')
+    strong = args.scaling == 'strong'
+    if strong and args.global_batch % world:
+        raise SystemExit('--global-batch must be a multiple of the number of GPUs')
+    per_gpu = args.global_batch // world if strong else args.batch_size
+    global_batch = per_gpu * world
+    leg = Leg(args, dev, rank, world, dist_on, shared_gpu, args.vocab, per_gpu, global_batch, args.shape)
+    res = leg.run(args.steps, args.warmup)
+    model, tok = leg.model, leg.tok
 
     # roofline pass: same steps with every launch bracketed by HIP events on its stream
     L = _lib.lib()
     L.psvae_profile_enable(1)
     for i in range(args.profile_steps):
-        step(args.warmup + args.steps + i)
+        leg.step(leg.next_step + i)
     torch.cuda.synchronize()
     raw = _lib.profile_collect()
     L.psvae_profile_enable(0)
@@ -373,15 +455,27 @@ def main():
     ev_ms = max(0.0, float(L.psvae_profile_event_overhead_ms(torch.cuda.current_stream().cuda_stream)))
     classes = {k: (max(ms - cnt * ev_ms, 0.05 * ms), work, cnt) for k, (ms, work, cnt) in raw.items()}
 
+    # the other curve: vocab 500, global batch 1024 split over the GPUs (1024 / N graphs per GPU)
+    strong_leg = None
+    if args.config3_steps > 0 and not (strong and args.vocab == 500 and args.global_batch == 1024) and 1024 % world == 0:
+        leg3 = Leg(args, dev, rank, world, dist_on, shared_gpu, 500, 1024 // world, 1024, 'zinc', n_distinct=4)
+        r3 = leg3.run(args.config3_steps, max(2, min(args.warmup, 10)))
+        strong_leg = {'workload': f'ZINC250K-shape training step, vocab 500, global batch 1024 = {1024 // world} graphs per GPU',
+                      'scaling': 'strong', 'n_gpus': world, 'value': r3['value'], 'unit': 'molecules/s',
+                      'ms_per_step': r3['ms_per_step'], 'steps': args.config3_steps, 'step_ms': r3['step_ms'],
+                      'host_enqueue_ms_per_step': r3['host_enqueue_ms_per_step'], 'final_loss': r3['final_loss'],
+                      'params': int(leg3.model._n_trained)}
+        del leg3
+
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
         return
-    ms_per_step = elapsed / args.steps * 1e3
-    dev_collate_ms = device_collate_ms(host_times['mols'], tok, dev, args.batch_size) if world == 1 and not args.no_bulk else None
+    ms_per_step = res['ms_per_step']
+    single = world == 1 and not dist_on
+    dev_collate_ms = device_collate_ms([m for ms in leg.mols for m in ms], tok, dev, per_gpu) if single and not args.no_bulk else None
     comm = 'RCCL' if args.backend == 'nccl' else args.backend
-    value = world * args.batch_size * args.steps / elapsed
     table = {}
     for name, (ms, work, cnt) in classes.items():
         per_launch_us = ms / cnt * 1e3
@@ -400,9 +494,10 @@ def main():
         achieved, peak, unit, bound = dwork / (dms * 1e-3) / 1e12, MFMA_F32_PEAK_TF, 'TFLOP/s', 'mfma'
     else:
         achieved, peak, unit, bound = dwork / (dms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s', 'hbm'
+    traffic = pmc_traffic(dom, args, per_gpu)
     roofline = {'kernel': dom, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
-                'traffic': pmc_traffic(dom, args), 'traffic_unit': 'HBM-side bytes per launch (rocprofv3 PMC, see traffic_source)',
-                'traffic_source': PMC_FILE if pmc_traffic(dom, args) is not None else None,
+                'traffic': traffic, 'traffic_unit': 'HBM-side bytes per launch (rocprofv3 PMC, see traffic_source)',
+                'traffic_source': PMC_FILE if traffic is not None else None,
                 'algorithmic_per_launch': dwork / dcnt, 'avg_launch_us': dms / dcnt * 1e3,
                 'event_pair_overhead_us_subtracted': ev_ms * 1e3,
                 'launches_per_step': dcnt / args.profile_steps}
@@ -410,28 +505,34 @@ def main():
     mp_ms = sum(classes[k][0] for k in mp)
     mp_bytes = sum(classes[k][1] for k in mp)
     out = {
-        'metric': 'train molecules/sec (enc+dec fwd+bwd), ZINC-shape', 'value': value, 'unit': 'molecules/s',
+        'metric': 'train molecules/sec (enc+dec fwd+bwd), ZINC-shape', 'value': res['value'], 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'step_ms': spread, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'ZINC250K-shape training step, vocab {args.vocab}, hidden 300, batch {args.batch_size} per GPU '
-                               f'(fwd + bwd + clip + Adam{f" + grad all-reduce over {comm}" if world > 1 else ""})',
-                   'global_batch': world * args.batch_size, 'parallelism': f'dp{world}', 'params': int(model._n_trained),
-                   'final_loss': final_loss, 'host_collate_ms_per_batch': collate_s * 1e3,
-                   'host_stage2_plus_3_ms_per_batch': host_times.get('per_item_ms'),
-                   'host_packed_dataset_ms_per_batch': host_times.get('packed_ms'),
+        'step_ms': res['step_ms'], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic', 'rccl_ranks': world if (dist_on and args.backend == 'nccl') else 0,
+        'config': {'workload': f'ZINC250K-shape training step, vocab {args.vocab}, hidden 300, batch {per_gpu} per GPU '
+                               f'(fwd + bwd + clip + Adam{f" + grad all-reduce over {comm}" if dist_on else ""})',
+                   'global_batch': global_batch, 'parallelism': f'dp{world}', 'params': int(model._n_trained),
+                   'grad_reduce': (type(leg.reducer).__name__ + f', denominators: {leg.denoms_mode}') if dist_on else None,
+                   'final_loss': res['final_loss'], 'host_collate_ms_per_batch': leg.collate_s * 1e3,
                    'device_collate_ms_per_batch': dev_collate_ms,
-                   'host_enqueue_ms_per_step': host_enqueue_s / args.steps * 1e3},
+                   'host_enqueue_ms_per_step': res['host_enqueue_ms_per_step']},
         'roofline': roofline,
         'message_passing': {'kernels': mp, 'bound': 'hbm', 'achieved': (mp_bytes / (mp_ms * 1e-3) / 1e9) if mp_ms else None,
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': (mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mp_ms else None},
         'kernel_classes': table,
     }
-    if world == 1 and not args.no_bulk:
+    if strong_leg is not None:
+        out['strong_scaling'] = strong_leg
+    if single and not args.no_bulk:
         out['message_passing']['bulk'] = bulk_message_passing(dev)
-    if world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
+        host_times = {}
+        make_batches(tok, args.vocab, args.shape, per_gpu, 2, seed=2021, host_times=host_times)
+        out['config']['host_stage2_plus_3_ms_per_batch'] = host_times.get('per_item_ms')
+        out['config']['host_packed_dataset_ms_per_batch'] = host_times.get('packed_ms')
         qm9, _ = make_batches(tok, args.vocab, 'qm9', 32, 1, seed=7)
-        out['cpu_baseline'] = cpu_baseline(cpu_batches[0], qm9[0], args.vocab)
+        out['cpu_baseline'] = cpu_baseline(leg.cpu_batches[0], qm9[0], args.vocab)
     result_out.write(json.dumps(out) + '\n')
     result_out.flush()
 

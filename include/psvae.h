@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 2
+#define PSVAE_ABI_VERSION 3
 
 enum {
     PSVAE_OK = 0,
@@ -128,6 +128,11 @@ typedef struct psvae_batch {
     const float *conds;          /* [B, G] or NULL */
     float *d_conds;              /* [B, G], backward output in decoder-only mode */
     const float *d_z;            /* [B, Z] or NULL */
+    /* Optional status words (device, 8 x int32, caller-zeroed; NULL = not reported).  Word 0 is set to 1 when a
+     * workgroup of the multi-CU GRU recurrence stopped waiting for its partners (its waits are bounded at 2 s so
+     * that a GPU which cannot keep the group resident cannot hang the process): that step's outputs are invalid.
+     * The library only ever sets it, so one buffer passed to every step accumulates over a whole run. */
+    int32_t *status;
 } psvae_batch;
 
 /* ---- whole training step ---------------------------------------------------
@@ -211,6 +216,15 @@ int psvae_sample_pieces(const psvae_dims* dims, const psvae_params* params, cons
 int psvae_score_links(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, const float* z,
                       void* workspace, size_t workspace_bytes, float* probs, float* confidence, int32_t* bond_type,
                       void* stream);
+
+/* ---- rsample's epsilon (src/modules/vae_piece_decoder.py:61: torch.randn_like) as a counter-based draw:
+ * out[r, c] (rows x width, contiguous) = the N(0,1) number that belongs to (seed, draw, first_row + r, c).
+ * Philox-4x32-10 with counter (c/4, row low, row high, draw low) and key (seed low, seed high ^ draw high); the
+ * four outputs become columns 4(c/4)..+3 by two Box-Muller transforms over 24-bit uniforms ((x>>8)+0.5)*2^-24.
+ * `first_row` is the GLOBAL index of the first graph, `draw` counts the forward passes: a data-parallel run then
+ * samples exactly what one process samples for the undivided batch, whatever the number of GPUs.  (The
+ * reference's draw comes from torch's global generator and depends on how graphs are dealt to processes.) */
+int psvae_normal_rows(uint64_t seed, uint64_t draw, int64_t first_row, int rows, int width, float* out, void* stream);
 
 /* ---- optimiser: clip_grad_norm_(10) + Adam (src/train.py:47; ps_vae_model.py:123-127)
  * over flat fp32 buffers of `count` elements.  `partials` is scratch of

@@ -430,3 +430,41 @@ def score_links(p, d, z, x, x_pieces, x_pos, edge_index, edge_attr, groups):
     h = F.linear(h, p['decoder.edge_predictor.0.seq.4.weight'], p['decoder.edge_predictor.0.seq.4.bias'])
     pred_edge = F.linear(h, p['decoder.edge_predictor.1.weight'], p['decoder.edge_predictor.1.bias'])
     return pred_edge_index, torch.softmax(pred_edge, dim=-1)
+
+
+def philox4x32_10(c, k0, k1):
+    """Philox-4x32-10 (Salmon et al., SC'11; constants of the Random123 library): `c` four uint64 arrays holding
+    32-bit counter words, `k0`, `k1` the key words.  Returns the four output words."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+    c = [np.asarray(w, dtype=np.uint64) & m32 for w in c]
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & m32, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return c
+
+
+def normal_rows(seed, draw, first_row, rows, width):
+    """Restatement of the library's counter-based epsilon draw (`psvae_normal_rows`): element (r, c) is a
+    function of (seed, draw, first_row + r, c) only.  Philox-4x32-10 with counter (c // 4, row low word, row
+    high word, draw low word) and key (seed low word, seed high word ^ draw high word); outputs (x0, x1),
+    (x2, x3) become columns 4g..4g+3 by Box-Muller over u = ((x >> 8) + 0.5) * 2^-24.  It stands where the
+    reference calls `torch.randn_like` (`src/modules/vae_piece_decoder.py:61`); the reference holds no vector
+    for it (its draw comes from torch's global generator), the generator itself is pinned by Random123's
+    known-answer vectors in the tests."""
+    import numpy as np
+    groups = (width + 3) // 4
+    r, g = np.meshgrid(np.arange(rows, dtype=np.uint64), np.arange(groups, dtype=np.uint64), indexing='ij')
+    row = r + np.uint64(first_row)
+    c = philox4x32_10([g, row & np.uint64(0xFFFFFFFF), row >> np.uint64(32), np.full_like(g, draw & 0xFFFFFFFF)],
+                      seed & 0xFFFFFFFF, ((seed >> 32) ^ (draw >> 32)) & 0xFFFFFFFF)
+    out = np.zeros((rows, groups * 4), dtype=np.float64)
+    for h in range(2):
+        u0 = ((c[2 * h] >> np.uint64(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+        u1 = ((c[2 * h + 1] >> np.uint64(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+        rad = np.sqrt(-2.0 * np.log(u0))
+        out[:, 2 * h::4] = rad * np.cos(2.0 * np.pi * u1)
+        out[:, 2 * h + 1::4] = rad * np.sin(2.0 * np.pi * u1)
+    return torch.from_numpy(out[:, :width].astype(np.float32))

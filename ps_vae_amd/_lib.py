@@ -74,7 +74,7 @@ BLOB_FIELDS = BATCH_PTRS
 
 class Batch(C.Structure):
     _fields_ = ([(k, i32) for k in ('B', 'n', 'E', 'E_in', 'S', 'L')] + [(k, vp) for k in BATCH_PTRS] +
-                [('props', vp), ('eps', vp), ('denoms', vp), ('conds', vp), ('d_conds', vp), ('d_z', vp)])
+                [('props', vp), ('eps', vp), ('denoms', vp), ('conds', vp), ('d_conds', vp), ('d_z', vp), ('status', vp)])
 
 
 class MolStore(C.Structure):
@@ -114,6 +114,7 @@ def lib():
     L.psvae_sample_pieces_workspace_bytes.argtypes = [P(Dims), C.c_int]
     L.psvae_sample_pieces.argtypes = [P(Dims), P(Params), vp, C.c_int, vp, C.c_int, f32, vp, vp, vp, C.c_int, vp, sz, vp]
     L.psvae_score_links.argtypes = [P(Dims), P(Params), P(Batch), vp, vp, sz, vp, vp, vp, vp]
+    L.psvae_normal_rows.argtypes = [C.c_uint64, C.c_uint64, i64, C.c_int, C.c_int, vp, vp]
     L.psvae_adam_partials.restype = sz
     L.psvae_adam_partials.argtypes = [i64]
     L.psvae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]
@@ -155,7 +156,7 @@ def lib():
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
     L.psvae_profile_event_overhead_ms.restype = C.c_double
     L.psvae_profile_event_overhead_ms.argtypes = [vp]
-    if L.psvae_abi_version() != 2:
+    if L.psvae_abi_version() != 3:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
     return L
@@ -164,7 +165,7 @@ def lib():
 EXPORTS = (
     'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward',
     'psvae_step_backward', 'psvae_step_backward_signal', 'psvae_streams_init', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
-    'psvae_score_links', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
+    'psvae_score_links', 'psvae_normal_rows', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',

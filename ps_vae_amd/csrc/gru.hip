@@ -216,7 +216,7 @@ __device__ __forceinline__ unsigned long long granule(unsigned tag, float v) {
 // one carries `tag`.  Gives up (returns false) when another wave has given up or after SPIN_LIMIT_TICKS.
 template <int N>
 __device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, unsigned tag, float (&v)[N], gu32* giveup,
-                                      int lane) {
+                                      gu32* sticky, int lane) {
     const unsigned long long t0 = wall_clock64();
     for (unsigned spins = 1;; ++spins) {
         bool ok = true;
@@ -231,7 +231,10 @@ __device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, 
         if ((spins & 63u) == 0u) {
             if (__hip_atomic_load(giveup, RLX_AGENT) != 0u) return false;
             if (wall_clock64() - t0 > SPIN_LIMIT_TICKS) {
-                if (lane == 0) __hip_atomic_store(giveup, 1u, RLX_AGENT);
+                if (lane == 0) {
+                    __hip_atomic_store(giveup, 1u, RLX_AGENT);
+                    if (sticky) __hip_atomic_store(sticky, 1u, RLX_AGENT);     // outlives the next clearing of the exchange buffer
+                }
                 return false;
             }
         }
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
                                                            const float* __restrict__ whh, const float* __restrict__ bhh,
                                                            float* __restrict__ hseq, float* __restrict__ hprev,
                                                            float* __restrict__ gates, unsigned long long* exch_,
-                                                           int B, int T, int R, int n_st) {
+                                                           int B, int T, int R, int n_st, unsigned int* sticky_) {
     __shared__ float red[2][4][3][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
     const int nks = R >> 2;
     const int cnt = nks > wave ? (nks - wave + 3) >> 2 : 0;        // this wave's K-steps: ks = wave + 4 i
     gu32* giveup = (gu32*)exch_;
+    gu32* sticky = (gu32*)sticky_;
     gu64* exch = (gu64*)exch_ + EXCH_HEADER_WORDS;
     const int ucol = min(j0 + j, R - 1);                           // B-operand column (columns >= R are discarded)
     float wr[KSW], wz[KSW], wn[KSW];
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
                 }
             } else if (cnt > 0) {
                 gu64* first = exch + ((long long)((t & 1) * n_st + st) * R + 4 * wave + kq) * 16 + j;
-                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)t, a, giveup, lane)) s_fail = 1;
+                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)t, a, giveup, sticky, lane)) s_fail = 1;
             }
             floatx4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
 #pragma unroll
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
                                                            const float* __restrict__ gates, const float* __restrict__ whh,
                                                            float* __restrict__ dgi, float* __restrict__ dgh,
                                                            float* __restrict__ dh0, unsigned long long* exch_,
-                                                           int B, int T, int R, int n_st) {
+                                                           int B, int T, int R, int n_st, unsigned int* sticky_) {
     __shared__ float red[2][4][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
     const int G = 3 * R, nks = G >> 2;
     const int cnt = nks > wave ? (nks - wave + 3) >> 2 : 0;
     gu32* giveup = (gu32*)exch_;
+    gu32* sticky = (gu32*)sticky_;
     gu64* exch = (gu64*)exch_ + EXCH_HEADER_WORDS;
     const int ucol = min(j0 + j, R - 1);
     float wb[KSW];
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
             for (int i = 0; i < KSW; ++i) a[i] = 0.f;
             if (cnt > 0) {
                 gu64* first = slab + (long long)(4 * wave + kq) * 16 + j;
-                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)(sidx + 1), a, giveup, lane)) s_fail = 1;
+                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)(sidx + 1), a, giveup, sticky, lane)) s_fail = 1;
             }
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -459,7 +464,7 @@ int gru_exchange_clear(hipStream_t s, void* exch, size_t exch_bytes, int B, int 
 }
 
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean) {
+            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean, int32_t* status) {
     if (B == 0 || T == 0) return 0;
     if (R % 4 || !aligned16(whh)) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, ntiles = R16 / 16;
@@ -474,10 +479,10 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
         const dim3 grid(ntiles, coop_slots(ntiles, n_st));
         if ((R >> 2) <= 52)
             hipLaunchKernelGGL(gru_fwd_coop_kernel<13>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
-                               (unsigned long long*)exch, B, T, R, n_st);
+                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
         else
             hipLaunchKernelGGL(gru_fwd_coop_kernel<16>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
-                               (unsigned long long*)exch, B, T, R, n_st);
+                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
         PSVAE_LAUNCH_CHECK();
         return 0;
     }
@@ -492,7 +497,8 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
 }
 
 int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
-            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean) {
+            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean,
+            int32_t* status) {
     if (B == 0) return 0;
     if (R % 4) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, G16 = (3 * R + 15) & ~15, ntiles = R16 / 16;
@@ -506,10 +512,10 @@ int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* 
         const dim3 grid(ntiles, coop_slots(ntiles, n_st));
         if ((3 * R >> 2) <= 152)
             hipLaunchKernelGGL(gru_bwd_coop_kernel<38>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,
-                               (unsigned long long*)exch, B, T, R, n_st);
+                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
         else
             hipLaunchKernelGGL(gru_bwd_coop_kernel<48>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,
-                               (unsigned long long*)exch, B, T, R, n_st);
+                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
         PSVAE_LAUNCH_CHECK();
         return 0;
     }

@@ -160,12 +160,15 @@ int fill_zero(hipStream_t s, float* p, int64_t count);
 int link_softmax(hipStream_t s, const float* logits, float* probs, float* conf, int32_t* type, int S);
 
 // ------------------------------------------------------------ GRU
-// `exch` (gru_exchange_bytes, 16-byte aligned, or NULL) enables the multi-CU recurrence
+// `exch` (gru_exchange_bytes, 16-byte aligned, or NULL) enables the multi-CU recurrence; `status` (device, or
+// NULL): word 0 is set to 1 when a workgroup of that recurrence stopped waiting for its partners
 size_t gru_exchange_bytes(int B, int T, int R);
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
-            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean = false);
+            float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean = false,
+            int32_t* status = nullptr);
 int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* gates, const float* whh,
-            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean = false);
+            float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exch, size_t exch_bytes, bool exch_clean = false,
+            int32_t* status = nullptr);
 // zero the exchange buffer ahead of time (then pass exch_clean = true)
 int gru_exchange_clear(hipStream_t s, void* exch, size_t exch_bytes, int B, int T, int R);
 

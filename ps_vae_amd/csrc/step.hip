@@ -241,15 +241,8 @@ std::mutex lanes_mu;
 Lanes* lanes_per_device[64] = {};
 int lanes_disabled = -1;
 
-// PSVAE_LANE_PRIORITY=1: lane 1 (GRU, on the critical path) gets the highest stream priority and lane 2
-// (weight-gradient products nobody waits for until the end of the step) the lowest.  Worth ~2 % on a
-// GPU this process owns; off by default because with a second process on the same GPU the
-// low-priority lane was observed never to finish.
-bool create_lane(hipStream_t* s, bool first) {
-    int least = 0, greatest = 0;
-    const char* pe = getenv("PSVAE_LANE_PRIORITY");
-    if (pe && pe[0] == '1') (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, first ? greatest : least) == hipSuccess;
+bool create_lane(hipStream_t* s) {
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
 }
 
 // One wave that keeps a compute unit busy for a fixed time (constant 100 MHz counter), for lanes_overlap().
@@ -267,6 +260,7 @@ bool lanes_overlap(hipStream_t a, hipStream_t b) {
         const auto t0 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, a, 10000LL);
         hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, b, 10000LL);
+        if (hipGetLastError() != hipSuccess) return true;        // no probe, no verdict: keep the streams as they are
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
@@ -281,14 +275,14 @@ Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!lanes_per_device[dev]) {
         Lanes* l = new Lanes();
-        bool ok = create_lane(&l->s1, true) && create_lane(&l->s2, false);
+        bool ok = create_lane(&l->s1) && create_lane(&l->s2);
         // With `probe`, a lane that shares its hardware queue with the caller's stream or with the other lane is
         // replaced by a newly created stream (which gets the next queue) until all three run side by side; the
         // rejected streams are kept until the search is over so that their queues stay taken.
         hipStream_t rejected[16]; int nrej = 0;
         for (int attempt = 0; ok && probe && attempt < 8; ++attempt) {
-            if (!lanes_overlap(caller, l->s1)) { rejected[nrej++] = l->s1; ok = create_lane(&l->s1, true); continue; }
-            if (!lanes_overlap(caller, l->s2) || !lanes_overlap(l->s1, l->s2)) { rejected[nrej++] = l->s2; ok = create_lane(&l->s2, false); continue; }
+            if (!lanes_overlap(caller, l->s1)) { rejected[nrej++] = l->s1; ok = create_lane(&l->s1); continue; }
+            if (!lanes_overlap(caller, l->s2) || !lanes_overlap(l->s1, l->s2)) { rejected[nrej++] = l->s2; ok = create_lane(&l->s2); continue; }
             break;
         }
         for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
@@ -423,7 +417,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     }
     // lane 1: GRU + vocabulary logits + piece loss rows
     PSVAE_TRY(rows_linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, w.scratch1, scf));
-    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true));
+    PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
     PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
     // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
@@ -469,7 +463,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
     if (L && hipStreamWaitEvent(s1, L->ev[14], 0) != hipSuccess) return (int)hipGetLastError();
-    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true));
+    PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     if ((long long)s.B * s.Z <= SMALL_LINEAR_OUTPUTS) PSVAE_TRY(small_linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z));
     else PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));

@@ -25,12 +25,19 @@ def _ptr(a):
 class NativeBatch:
     """Packed index blob + float side inputs of one batch (host or device)."""
 
-    def __init__(self, blob, offsets, sizes, props_sel, denoms):
+    def __init__(self, blob, offsets, sizes, props_sel, denoms, local_denoms=None, graph_base=None):
         self.blob = blob              # int32 tensor
         self.offsets = offsets        # list of int (words)
         self.sizes = sizes            # dict B,n,E,E_in,S,L
         self.props = props_sel        # float32 [B, n_props]
-        self.denoms = denoms          # float32 [4]: target tokens, S, B, B*n_props
+        # float32 [4]: target tokens, S, B, B*n_props.  `denoms` is what the kernels divide the loss sums by: this
+        # batch's own counts, or - written there by a data-parallel loop - the counts of the global batch;
+        # `local_denoms` always keeps this batch's own counts (a resident batch can be re-reduced every epoch).
+        self.denoms = denoms
+        self.local_denoms = denoms.clone() if local_denoms is None else local_denoms
+        # index of this batch's first graph inside the global batch it is a shard of (keys the epsilon draw);
+        # None = not sharded by the loader
+        self.graph_base = graph_base
         self._struct = None
 
     @property
@@ -42,12 +49,13 @@ class NativeBatch:
             return self
         nb = NativeBatch(self.blob.to(device, non_blocking=non_blocking), self.offsets, self.sizes,
                          self.props.to(device, non_blocking=non_blocking),
-                         self.denoms.to(device, non_blocking=non_blocking))
+                         self.denoms.to(device, non_blocking=non_blocking),
+                         self.local_denoms.to(device, non_blocking=non_blocking), self.graph_base)
         return nb
 
     def pin_memory(self):
         return NativeBatch(self.blob.pin_memory(), self.offsets, self.sizes, self.props.pin_memory(),
-                           self.denoms.pin_memory())
+                           self.denoms.pin_memory(), self.local_denoms.pin_memory(), self.graph_base)
 
     def field(self, name):
         """int32 view of one blob field (for tests)."""
@@ -55,7 +63,7 @@ class NativeBatch:
         end = self.offsets[i + 1] if i + 1 < len(self.offsets) else self.blob.numel()
         return self.blob[self.offsets[i]:end]
 
-    def struct(self, eps=None):
+    def struct(self, eps=None, status=None):
         """ctypes psvae_batch pointing into this batch's (device) memory."""
         if self._struct is None:
             s = _lib.Batch()
@@ -68,6 +76,7 @@ class NativeBatch:
             s.denoms = self.denoms.data_ptr()
             self._struct = s
         self._struct.eps = eps.data_ptr() if eps is not None else None
+        self._struct.status = status.data_ptr() if status is not None else None
         return self._struct
 
 

@@ -19,12 +19,13 @@ from .modules import Encoder, Predictor, VAEPieceDecoder
 
 # flat-buffer order: buckets in the order backward finishes them
 FLAT_ORDER = [
-    # bucket 0: property head, piece branch
-    'predictor.mlp.0.weight', 'predictor.mlp.0.bias', 'predictor.mlp.2.weight', 'predictor.mlp.2.bias',
-    'predictor.output.weight', 'predictor.output.bias', 'decoder.to_vocab.weight', 'decoder.to_vocab.bias',
+    # bucket 0: piece branch (final once lane 1 has run the GRU's backward and its weight gradients)
+    'decoder.to_vocab.weight', 'decoder.to_vocab.bias',
     'decoder.rnn.weight_ih_l0', 'decoder.rnn.weight_hh_l0', 'decoder.rnn.bias_ih_l0', 'decoder.rnn.bias_hh_l0',
     'decoder.latent_to_rnn_hidden.weight', 'decoder.latent_to_rnn_hidden.bias',
-    # bucket 1: link scorer
+    # bucket 1: property head and link scorer (lane 2, beside the scorer's input-gradient chain)
+    'predictor.mlp.0.weight', 'predictor.mlp.0.bias', 'predictor.mlp.2.weight', 'predictor.mlp.2.bias',
+    'predictor.output.weight', 'predictor.output.bias',
     'decoder.edge_predictor.0.seq.0.weight', 'decoder.edge_predictor.0.seq.0.bias',
     'decoder.edge_predictor.0.seq.2.weight', 'decoder.edge_predictor.0.seq.2.bias',
     'decoder.edge_predictor.0.seq.4.weight', 'decoder.edge_predictor.0.seq.4.bias',
@@ -42,7 +43,7 @@ FLAT_ORDER = [
     'encoder.node_trans.bias', 'decoder.graph_embedding.node_trans.bias',
     'decoder.atom_embedding.weight', 'decoder.piece_embedding.weight', 'decoder.pos_embedding.weight',
 ]
-BUCKET_STARTS = ['predictor.mlp.0.weight', 'decoder.edge_predictor.0.seq.0.weight', 'decoder.W_mean.weight',
+BUCKET_STARTS = ['decoder.to_vocab.weight', 'predictor.mlp.0.weight', 'decoder.W_mean.weight',
                  'encoder.conv.nn.seq.0.weight']
 # never used by the training step (the decoder-side encoder's `linear`): no gradient, not optimised
 UNTRAINED = ['decoder.graph_embedding.linear.weight', 'decoder.graph_embedding.linear.bias']
@@ -53,7 +54,7 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, trigger, model, nb, eps, weights):
         L = _lib.lib()
         dims, params = model._dims, model._params_struct
-        bs = nb.struct(eps)
+        bs = nb.struct(eps, model._status_words(eps.device))
         nbytes = L.psvae_workspace_bytes(C.byref(dims), C.byref(bs))
         if nbytes == 0:
             raise RuntimeError('psvae_workspace_bytes rejected the model/batch sizes (hidden, latent and rnn sizes '
@@ -93,7 +94,7 @@ class _StepFn(torch.autograd.Function):
                 g = g.clone()
                 g[5] += g_total
         grads_struct, fresh = model._grad_target()
-        bs = nb.struct(ctx.eps)
+        bs = nb.struct(ctx.eps, model._status_words(ctx.eps.device))
         stream = torch.cuda.current_stream().cuda_stream
         ev = model._early_events
         _lib.check(L.psvae_step_backward_signal(C.byref(model._dims), C.byref(model._params_struct), C.byref(bs),
@@ -129,6 +130,11 @@ class PSVAEModel(nn.Module):
         self._g6 = None
         self._unit = None
         self._early_events = None
+        self._status = None
+        self.last_backward_signalled = False
+        # epsilon of rsample: counter-based, keyed by (eps_seed, number of forward passes so far, global graph index)
+        self.eps_seed = int(config.get('seed', 2021)) if hasattr(config, 'get') else 2021
+        self.eps_draws = 0
         self._dims = self._make_dims()
 
     # ------------------------------------------------------------------ layout
@@ -196,9 +202,9 @@ class PSVAEModel(nn.Module):
         return s
 
     def _sync_flat(self):
-        p0 = self.predictor.mlp[0].weight
+        p0 = self.decoder.to_vocab.weight
         if (self._flat is None or p0.device != self._flat.device or
-                p0.data_ptr() != self._flat.data_ptr() + 4 * self._offsets['predictor.mlp.0.weight']):
+                p0.data_ptr() != self._flat.data_ptr() + 4 * self._offsets['decoder.to_vocab.weight']):
             self._flatten()
         elif p0.grad is None:
             named = dict(self.named_parameters())
@@ -220,11 +226,12 @@ class PSVAEModel(nn.Module):
         return self._gflat, self._gflat[self._n_trained:]
 
     def early_gradient_events(self):
-        """Two CUDA events that every following backward records as soon as the gradients of the flat range
-        `[0, bucket_bounds[3])` (everything but the GINE stacks, node_trans and the embedding tables) are
-        final, while the rest of backward is still running: a data-parallel caller waits for both on its
-        communication stream and starts that range's all-reduce early (`parallel.GradReducer.reduce_grads_early`).
-        Only the first backward after `zero_grad` writes the flat buffer directly, so only that one signals."""
+        """Two CUDA events that every following backward records while it is still running: the first once the
+        gradients of the flat range `[0, bucket_bounds[1])` (piece branch) are final, the second once those of
+        `[bucket_bounds[1], bucket_bounds[3])` (property head, link scorer, latent head, encoder.linear) are.
+        A data-parallel caller waits for them on its communication stream and starts those ranges'
+        all-reduces early (`parallel.OverlappedReducer`).  Only the first backward after `zero_grad` writes the
+        flat buffer directly, so only that one signals (`last_backward_signalled`)."""
         self._sync_flat()
         if self._early_events is None:
             self._early_events = (torch.cuda.Event(), torch.cuda.Event())
@@ -246,6 +253,7 @@ class PSVAEModel(nn.Module):
         return self._gtmp_struct, False
 
     def _grad_written(self, fresh):
+        self.last_backward_signalled = bool(fresh and self._early_events is not None)
         if not fresh:
             self._gflat.add_(self._gtmp)   # gradient accumulation across backward calls
         self._grads_fresh = False
@@ -268,9 +276,8 @@ class PSVAEModel(nn.Module):
         if not self._flat.is_cuda:
             raise RuntimeError('PSVAEModel runs on the GPU only: move it with .cuda() (no CPU implementation exists)')
         nb = self._native(batch)
-        B = nb.sizes['B']
         if eps is None:
-            eps = torch.randn(B, self._dims.latent, dtype=torch.float32, device=self._flat.device)
+            eps = self.draw_eps(nb.sizes['B'], nb.graph_base or 0)
         eps = eps.to(self._flat.device, torch.float32).contiguous()
         alpha = float(self.config['alpha'])
         out, self._last_total = _StepFn.apply(self._trigger, self, nb, eps, (1.0 - alpha, alpha, float(self.cal_beta())))
@@ -278,6 +285,18 @@ class PSVAEModel(nn.Module):
         if return_accu:
             return pred_loss, (losses, self._accuracies(nb))
         return pred_loss, losses
+
+    def draw_eps(self, rows, first_row=0):
+        """The N(0,1) draw of `rsample` (`src/modules/vae_piece_decoder.py:61`) for graphs `first_row ..
+        first_row + rows` of the global batch, as a counter-based function of (`eps_seed`, `eps_draws`, graph,
+        column): ranks that hold shards of one global batch draw what a single process would draw for all of it.
+        Every call advances `eps_draws` (one draw per forward pass)."""
+        dev = self._flat.device if self._flat is not None else next(self.parameters()).device
+        out = torch.empty(rows, self._dims.latent, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().psvae_normal_rows(self.eps_seed, self.eps_draws, int(first_row), rows, self._dims.latent,
+                                                out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), 'psvae_normal_rows')
+        self.eps_draws += 1
+        return out
 
     def _ws_view(self, name, rows, cols, ld=None):
         ws, nb = self._last_ws
@@ -316,16 +335,24 @@ class PSVAEModel(nn.Module):
             self._unit = (torch.ones((), dtype=torch.float32, device=dev), g6)
         return self._unit[0]
 
-    def recurrence_gave_up(self):
-        """True if a workgroup of the multi-CU GRU recurrence of the most recent step stopped waiting for its
-        partners (its waits are bounded so that a GPU that cannot keep the group resident cannot hang the
-        process; the step's results are then meaningless).  Synchronises the device."""
-        if self._last_ws is None:
+    def _status_words(self, device):
+        if self._status is None or self._status.device != device:
+            self._status = torch.zeros(8, dtype=torch.int32, device=device)
+        return self._status
+
+    def recurrence_gave_up(self, clear=False):
+        """True if, in any step since the model was built (or since the last call with `clear`), a workgroup of
+        the multi-CU GRU recurrence stopped waiting for its partners (its waits are bounded so that a GPU that
+        cannot keep the group resident cannot hang the process; that step's results are meaningless).  The
+        kernels set a status word that nothing clears in between, so one check covers every step so far.
+        Synchronises the device."""
+        if self._status is None:
             return False
-        ws, nb = self._last_ws
-        off = _lib.lib().psvae_workspace_offset(C.byref(self._dims), C.byref(nb.struct()), b'gru_exchange')
-        torch.cuda.synchronize()
-        return bool(ws.view(torch.int32)[off].item() != 0)
+        torch.cuda.synchronize(self._status.device)
+        gave_up = bool(self._status[0].item() != 0)
+        if clear:
+            self._status.zero_()
+        return gave_up
 
     def activation(self, name, rows, cols, ld=None):
         """View of a saved activation of the most recent forward (tests, debugging)."""
@@ -386,8 +413,10 @@ class PSVAEModel(nn.Module):
         """`ps_vae_model.py:160-170`: a sample z = mean + exp(log_var / 2) * eps."""
         with torch.no_grad():
             mean, lvar = self.encode(batch)
-            eps = torch.randn_like(mean) if eps is None else eps.to(mean.device)
-            return mean + torch.exp(lvar / 2) * eps
+            if eps is None:
+                nb = self._native(batch)
+                eps = self.draw_eps(mean.shape[0], nb.graph_base or 0)
+            return mean + torch.exp(lvar / 2) * eps.to(mean.device)
 
     def sample_z(self, n, device=None):
         return torch.randn(n, self.decoder.latent_dim, device=device if device is not None else self._flat.device)

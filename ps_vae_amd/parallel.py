@@ -32,7 +32,7 @@ class GradReducer:
     ~7.6 MB, so the transfer is latency-bound: as long as the collectives run
     after backward (not overlapped with it) ONE bucket `[0, n]` is the fastest
     choice; `model.bucket_bounds` lists where backward finishes groups of
-    parameters, for callers that overlap."""
+    parameters, for callers that overlap (`OverlappedReducer`, the default of `make_reducer`)."""
 
     def __init__(self, bounds, group=None, always=False):
         self.bounds = list(bounds)
@@ -72,38 +72,67 @@ class GradReducer:
 
 
 class OverlappedReducer(GradReducer):
-    """Gradient all-reduce in two messages, the first of them overlapped with backward: the model's backward
-    signals (two events) when the gradients of its flat range `[0, split)` are final, which is before the
-    GINE stacks' backward has run; that range is reduced on a side stream meanwhile, the rest after backward.
+    """Gradient all-reduce in three messages in the order backward finishes them, the first two overlapped
+    with the rest of backward.  The model's backward records an event once the piece branch's gradients (flat
+    range `[0, b1)`, 1.0 MB) are final and another once those of the property head, link scorer, latent head and
+    encoder.linear (`[b1, b3)`, 4.5 MB) are - both while the GINE stacks' backward, more than half of the
+    backward pass, has not started; each range is reduced on a side stream as soon as its event fires, and the
+    rest (`[b3, n)`, 2.1 MB: GINE stacks, node_trans, embedding tables) after backward.  xGMI moves such
+    messages in a few tens of microseconds each, so the point of the split is to hide the first 5.5 MB behind
+    compute, not to pipeline the wire.  `tail` extra elements behind the gradients (see
+    `PSVAEModel.grad_message`) travel with the last message.
 
         red = OverlappedReducer(model)
         loss.backward(); red.reduce(); opt.step()
-    """
 
-    def __init__(self, model, group=None, always=False):
-        model.flat_buffers()
-        super().__init__([0, model.bucket_bounds[3], model._n_trained], group, always)
-        self.model = model
+    The result is bit-identical to one all-reduce over the whole buffer (element-wise sums, same ranks)."""
+
+    def __init__(self, model, group=None, always=False, tail=0):
+        grads = model.grad_message()[0]
+        b = model.bucket_bounds
+        super().__init__([b[0], b[1], b[3], b[4] + int(tail)], group, always)
+        if b[4] + int(tail) > grads.numel():
+            raise ValueError('tail exceeds the spare floats behind the gradient buffer')
+        self.model, self.message = model, grads
         self.events = model.early_gradient_events()
-        self.comm = torch.cuda.Stream(device=model.flat_buffers()[1].device)
+        self.comm = torch.cuda.Stream(device=grads.device) if grads.is_cuda else None
 
     def reduce(self):
-        """Call after `backward`; returns when both collectives are queued and the current stream waits for them."""
+        """Call after `backward`; returns when the three collectives are queued and the current stream waits
+        for them."""
         if not self.active:
             return
-        grads = self.model.flat_buffers()[1]
-        lo, mid, hi = self.bounds
+        model = self.model
+        grads = model.grad_message()[0]
+        b0, b1, b2, b3 = self.bounds
         cur = torch.cuda.current_stream()
-        for e in self.events:
-            self.comm.wait_event(e)
-        with torch.cuda.stream(self.comm):
-            early = self._all_reduce(grads[lo:mid], async_op=True)
-        late = self._all_reduce(grads[mid:hi], async_op=True)       # queued behind backward on the current stream
-        if early is not None:
-            early.wait()            # the side stream waits for the collective ...
-        cur.wait_stream(self.comm)  # ... and the current stream for the side stream
-        if late is not None:
-            late.wait()
+        if not model.last_backward_signalled:
+            # an accumulating backward (or one before the events existed) signals nothing: everything is final
+            # only once the current stream gets here
+            self.comm.wait_stream(cur)
+        works = []
+        for event, lo, hi in ((self.events[0], b0, b1), (self.events[1], b1, b2)):
+            if model.last_backward_signalled:
+                self.comm.wait_event(event)
+            with torch.cuda.stream(self.comm):
+                works.append(self._all_reduce(grads[lo:hi], async_op=True))
+        works.append(self._all_reduce(grads[b2:b3], async_op=True))      # queued behind backward on the current stream
+        for w in works:
+            if w is not None:
+                w.wait()            # the current stream waits for the collective (it runs on the backend's own stream)
+        cur.wait_stream(self.comm)  # and for whatever the side stream itself carried (host-staged copies)
+
+
+def make_reducer(model, group=None, always=False, overlap=None):
+    """The reducer a data-parallel loop should use: three messages overlapped with backward when the model lives
+    on a GPU (`PSVAE_DP_OVERLAP=0` or `overlap=False` selects the single message after backward)."""
+    import os
+    model.flat_buffers()
+    if overlap is None:
+        overlap = os.environ.get('PSVAE_DP_OVERLAP', '1') != '0'
+    if overlap and model.flat_buffers()[1].is_cuda:
+        return OverlappedReducer(model, group, always)
+    return GradReducer([0, model._n_trained], group, always)
 
 
 def global_step_reference(loss_sums_per_rank, counts_per_rank):

@@ -54,7 +54,7 @@ class Tokenizer:
     def __init__(self, vocab_path=None, pieces=None):
         """`vocab_path`: a vocabulary file of either format; or pass `pieces`,
         a list of (smiles, n_atoms, freq), directly."""
-        self.kekulize = None
+        self.kekulize = None        # the ps format's header flag; None for the header-less src format
         if pieces is None:
             with open(vocab_path, 'r') as fin:
                 lines = fin.read().strip().split('\n')
@@ -76,6 +76,10 @@ class Tokenizer:
             self.idx2piece.append(smi)
         self.atom_pad = '<pad>'
         self.chem_vocab = GeneralVocab(atom_special=[self.atom_pad])
+        # names the stand-alone miner's Tokenizer uses for the same tables (ps/mol_bpe.py:185-204)
+        self.idx2subgraph, self.subgraph2idx = self.idx2piece, self.piece2idx
+        self.bond_start = '<bstart>'
+        self.max_num_nodes = max([n for _, n, _ in pieces], default=0) + 2     # + start, padding
 
     @classmethod
     def synthetic(cls, vocab_size):
@@ -93,6 +97,18 @@ class Tokenizer:
 
     def piece_to_idx(self, piece):
         return self.piece2idx[piece]
+
+    # the same two accessors under the names of ps/mol_bpe.py:245-249,260-261
+    idx_to_subgraph, subgraph_to_idx = idx_to_piece, piece_to_idx
+
+    def num_subgraph_type(self):
+        return len(self.idx2piece)
+
+    def atom_pos_pad_idx(self):
+        return self.max_num_nodes - 1
+
+    def atom_pos_start_idx(self):
+        return self.max_num_nodes - 2
 
     def pad_idx(self):
         return self.piece2idx[self.pad]

@@ -107,32 +107,50 @@ def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3
     KL-aware early stopping.  Returns the per-epoch validation records.
 
     Data-parallel (no reference counterpart; its Lightning 'dp' mode mis-splits the batch dict, `src/train.py:49-50`):
-    pass a `parallel.GradReducer` and give every rank loaders over its own shard of the graphs, with the same
-    number of batches on every rank.  Each step then divides the local loss sums by the global counts and sums
+    pass `parallel.make_reducer(model)` (or a `GradReducer`) and give every rank loaders over its own shard of
+    the graphs, with the same number of batches on every rank.  Each step then divides the local loss sums by the global counts and sums
     the flat gradient over ranks, which is the step of the undivided batch; validation records are means over
     all ranks, so every rank takes the same early-stopping decision, and rank 0 alone writes the checkpoint."""
     opt = model.configure_optimizers()
     stopper = VAEEarlyStopping(finish_anneal_step(model.config), patience=patience)
     history, best = [], math.inf
     dp = reducer is not None and reducer.active
-    writer = not dp or torch.distributed.get_rank(reducer.group) == 0
+    rank = torch.distributed.get_rank(reducer.group) if dp else 0
+    writer = rank == 0
     for epoch in range(max_epochs):
         opt.set_epoch(epoch)
+        # a new order (and new negative pairs) every epoch, as DataLoader(shuffle=True) and the reference's
+        # collate give: loaders that key their order on an epoch number are told it
+        for obj in (train_loader, getattr(train_loader, 'sampler', None), getattr(train_loader, 'batch_sampler', None)):
+            if hasattr(obj, 'set_epoch'):
+                obj.set_epoch(epoch)
         for batch in train_loader:
             batch = to_device(batch, device)
             if dp:
                 if '_native' not in batch:
                     raise ValueError('data-parallel fit needs batches from BPEMolDataset, PackedMolDataset '
                                      'or DeviceLoader (their loss denominators are exchanged between ranks)')
-                denoms = batch['_native'].denoms
-                reducer.reduce_denoms(denoms.clone(), out=denoms)
+                nb = batch['_native']
+                # global counts from every rank's OWN counts (kept apart, so a resident batch that comes round
+                # again next epoch is reduced from the same numbers)
+                reducer.reduce_denoms(nb.local_denoms, out=nb.denoms)
+                if nb.graph_base is None:       # shard position inside the global batch, for the epsilon draw
+                    nb.graph_base = rank * nb.sizes['B']
             opt.zero_grad()
             loss = model.training_step(batch)
             loss.backward(model.unit_grad())
             if dp:
-                reducer.reduce_grads(model.flat_buffers()[1])
+                if hasattr(reducer, 'reduce'):
+                    reducer.reduce()
+                else:
+                    reducer.reduce_grads(model.flat_buffers()[1])
             opt.step()
             model.global_step += 1
+        # the multi-CU recurrence bounds its waits; a step in which a workgroup gave up holds garbage, and the
+        # parameters must not be validated or saved (checked here, where the host synchronises anyway)
+        if model.recurrence_gave_up():
+            raise RuntimeError(f'epoch {epoch}: the multi-CU GRU recurrence timed out during a training step (GPU shared '
+                               'with another process?); parameters are invalid. Set PSVAE_GRU_MULTI_CU=0 on a shared GPU.')
         rec = validate(model, valid_loader, device, reducer)
         rec.update(epoch=epoch, global_step=model.global_step)
         history.append(rec)

@@ -13,19 +13,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(300)
-def test_bench_two_ranks_over_gloo():
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it and no WORLD_SIZE in the environment: the program
+    itself starts the two rank processes; its standard output is rank 0's single result line, for the whole job."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--backend', 'gloo',
+           '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--config3-steps', '3']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['global_batch'] == 256
+    assert res['rccl_ranks'] == 0                        # gloo rehearsal: no RCCL rank took part
+    assert res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']   # finite, not NaN
+    assert res['roofline']['frac'] > 0
+    strong = res['strong_scaling']                       # vocab 500, global batch 1024 -> 512 graphs per rank
+    assert strong['scaling'] == 'strong' and '512 graphs per GPU' in strong['workload'] and strong['value'] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_under_a_launcher():
+    """The driver's form: torch.distributed.run starts the ranks, bench.py reads RANK / WORLD_SIZE."""
     env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--backend', 'gloo', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1']
+           '--backend', 'gloo', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--scaling', 'strong',
+           '--global-batch', '96', '--vocab', '500', '--config3-steps', '0']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['global_batch'] == 256
-    assert res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']   # finite, not NaN
-    assert res['roofline']['frac'] > 0
+    assert res['n_gpus'] == 2 and res['scaling'] == 'strong' and res['config']['global_batch'] == 96
+    assert 'batch 48 per GPU' in res['config']['workload'] and res['value'] > 0
 
 
 @pytest.mark.timeout(300)
@@ -42,10 +64,10 @@ def test_bench_collectives_over_rccl_with_one_rank():
     assert res['n_gpus'] == 1 and res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']
 
 
-def _run(env_extra, ranks, backend, port):
+def _run(env_extra, ranks, backend, port, extra=()):
     env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200', **env_extra)
     tail = [os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6', '--warmup', '2', '--backend', backend,
-            '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1']
+            '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--config3-steps', '0'] + list(extra)
     if ranks > 1:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
                '127.0.0.1', '--master-port', str(port)] + tail
@@ -59,11 +81,19 @@ def _run(env_extra, ranks, backend, port):
 
 @pytest.mark.timeout(600)
 def test_overlapped_gradient_reduce_gives_the_same_run():
-    """Two gradient messages, the first started while backward is still running (on the events the step
-    records), must leave the run exactly where the single message after backward leaves it."""
-    plain = _run({}, 2, 'gloo', 29541)
-    early = _run({'PSVAE_BENCH_OVERLAP': '1'}, 2, 'gloo', 29543)
+    """Three gradient messages, the first two started while backward is still running (on the events the step
+    records: the default), must leave the run exactly where the single message after backward leaves it; and two
+    ranks on the halves of a batch must end where one process ends on the whole batch (same graphs, same
+    negative pairs, same epsilon per graph), up to the order of fp32 sums."""
+    early = _run({}, 2, 'gloo', 29543)
+    plain = _run({'PSVAE_DP_OVERLAP': '0'}, 2, 'gloo', 29541)
+    assert 'OverlappedReducer' in early['config']['grad_reduce'] and 'GradReducer' in plain['config']['grad_reduce']
     assert early['config']['final_loss'] == plain['config']['final_loss']
-    rccl = _run({'PSVAE_BENCH_FORCE_DIST': '1', 'PSVAE_BENCH_OVERLAP': '1'}, 1, 'nccl', 29545)
+    once = _run({'PSVAE_BENCH_DENOMS': 'once'}, 2, 'gloo', 29549)
+    assert once['config']['final_loss'] == plain['config']['final_loss']
+    rccl = _run({'PSVAE_BENCH_FORCE_DIST': '1'}, 1, 'nccl', 29545)
     single = _run({}, 1, 'nccl', 29547)
+    assert rccl['rccl_ranks'] == 1 and single['rccl_ranks'] == 0
     assert rccl['config']['final_loss'] == single['config']['final_loss']
+    whole = _run({}, 1, 'nccl', 29551, extra=['--batch-size', '256'])
+    assert abs(early['config']['final_loss'] - whole['config']['final_loss']) <= 2e-4 * abs(whole['config']['final_loss'])

@@ -44,8 +44,15 @@ def fp64_grads(d, sd, ref_batch, eps):
     return {n: tr.p[n].grad for n in tr.names}
 
 
-def compare_forward_backward(model, d, sd, ref_batch, batch, eps, with_fp64=False):
+# Gradient tensors (of 47) that may need the float64 yardstick instead of the flat band, per case.  Printed by
+# every run (`pytest -s`); measured: 0 for the reference fixtures, 0 / 1 / 2 for the three benchmark shapes.
+MAX_FP64_FALLBACKS = 3
+
+
+def compare_forward_backward(model, d, sd, ref_batch, batch, eps, with_fp64=False, fallbacks=None):
+    """`fallbacks` (list) receives the names of the gradients that were only accepted against float64."""
     tr = O.Trainer(sd, d)
+    fallbacks = [] if fallbacks is None else fallbacks
     g64 = fp64_grads(d, sd, ref_batch, eps) if with_fp64 else None
     keep = {}
     losses_ref = O.forward(tr.p, d, ref_batch, eps, keep)
@@ -106,6 +113,10 @@ def compare_forward_backward(model, d, sd, ref_batch, batch, eps, with_fp64=Fals
                 e_hip = float((named[name].grad.detach().double().cpu() - exact).abs().max())
                 e_ref = float((g_ref.double() - exact).abs().max())
                 assert e_hip <= max(4 * e_ref, 2e-3 * float(exact.abs().max())), (name, e_hip, e_ref)
+                fallbacks.append((name, e_hip, e_ref))
+    print(f'gradients accepted against the float64 yardstick: {len(fallbacks)} of {len(tr.names)}: '
+          + ', '.join(f'{n} (hip {a:.2e}, fp32 oracle {b:.2e})' for n, a, b in fallbacks))
+    assert len(fallbacks) <= MAX_FP64_FALLBACKS, fallbacks
     return tr
 
 
@@ -221,6 +232,48 @@ def test_module_level_encoder_matches_oracle():
     q = torch.relu(torch.nn.functional.linear(q, sd['predictor.mlp.2.weight'], sd['predictor.mlp.2.bias']))
     want = torch.nn.functional.linear(q, sd['predictor.output.weight'], sd['predictor.output.bias'])
     check_close(model.predictor(z.cuda()), want, 'predictor')
+
+
+def test_encoder_forward_on_a_pyg_style_batch():
+    """`Encoder.forward(batch, return_x)` (`src/modules/encoder.py:71-80`): the PyG-`Batch` flavour takes packed
+    nodes (`x`, `edge_index`, one-hot `edge_attr`), the graph of each node in `batch.batch` and `num_graphs`;
+    no padding mask.  Checked against the oracle's embed_node + embed_graph on the same arrays, values and
+    gradients, including a graph without bonds and `return_x=True`."""
+    from types import SimpleNamespace
+    from ps_vae_amd import synth
+    d, V = O.default_dims(300), 300
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(63, 'qm9', V, 6)
+    mols[2] = dict(mols[2], edge_index=[], edge_attr=[])             # an edgeless graph in the middle
+    src, dst, typ, gid, off = [], [], [], [], 0
+    for i, m in enumerate(mols):
+        for (a, b), ty in zip(m['edge_index'], m['edge_attr']):
+            src += [a + off, b + off]; dst += [b + off, a + off]; typ += [ty, ty]
+        gid += [i] * len(m['x'])
+        off += len(m['x'])
+    n = off
+    x0 = torch.randn(n, 200, generator=torch.Generator().manual_seed(8))
+    edge_index = torch.tensor([src, dst], dtype=torch.long)
+    edge_attr = torch.nn.functional.one_hot(torch.tensor(typ), 4)
+    gid = torch.tensor(gid)
+    p = {k: v.clone().requires_grad_(not k.endswith('eps')) for k, v in sd.items()}
+    layers = O.embed_node(x0, edge_index, edge_attr, p, 'encoder.', 4)
+    _, res_ref = O.embed_graph(torch.cat(layers[1:], -1), gid, torch.zeros(n, dtype=torch.bool), p, 'encoder.')
+    (res_ref.sum() + layers[-1].pow(2).sum()).backward()
+    for q in model.parameters():
+        q.grad = None
+    batch = SimpleNamespace(x=x0.cuda(), edge_index=edge_index.cuda(), edge_attr=edge_attr.cuda(), batch=gid.cuda(),
+                            num_graphs=len(mols))
+    res, x_last = model.encoder(batch, return_x=True)
+    assert tuple(res.shape) == (len(mols), d['graph']) and tuple(x_last.shape) == (n, d['hidden'])
+    check_close(res, res_ref, 'Encoder.forward graph embedding')
+    check_close(x_last, layers[-1], 'Encoder.forward last-layer x')
+    assert torch.equal(model.encoder(batch), res)                    # return_x=False: the embedding alone
+    (res.sum() + x_last.pow(2).sum()).backward()
+    for name in ('node_trans.weight', 'node_trans.bias', 'edge_trans.weight', 'conv.nn.seq.0.weight', 'conv.nn.seq.2.weight',
+                 'linear.weight', 'linear.bias'):
+        check_close(dict(model.encoder.named_parameters())[name].grad, p['encoder.' + name].grad, f'grad {name}',
+                    atol_scale=5e-5)
 
 
 def test_training_step_total_equals_weighted_loss():

@@ -15,8 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(300)
 def test_fit_two_ranks_equals_the_undivided_batches(tmp_path):
-    from ps_vae_amd import Tokenizer, synth
-    from ps_vae_amd.data import get_dataloader, to_device
+    from ps_vae_amd import Tokenizer
     from tests import dp_fit_worker as W
     out = str(tmp_path / 'dp')
     os.makedirs(out + '.ckpt', exist_ok=True)
@@ -30,27 +29,41 @@ def test_fit_two_ranks_equals_the_undivided_batches(tmp_path):
     assert got[0]['history'] == got[1]['history'], 'ranks must see the same validation record'
     assert os.path.exists(os.path.join(out + '.ckpt', 'best.ckpt'))
 
-    # the same three steps in one process
+    # resident batches come round again in the second epoch: their global counts must still be the sum of the two
+    # ranks' own counts, not that sum multiplied up once more
+    assert torch.equal(got[0]['denoms'], got[0]['local_denoms'] + got[1]['local_denoms'])
+    assert torch.equal(got[0]['denoms'], got[1]['denoms'])
+
+    # the same steps in one process: every step takes both ranks' batches (the second backward accumulates) with the
+    # global counts, and each graph gets the epsilon of its place in the global batch
     tok = Tokenizer.synthetic(W.V)
-    mols = synth.make_molecules(1, 'qm9', W.V, 2 * W.PER_RANK * W.STEPS)
-    batches = []
-    for r in range(2):
-        random.seed(7 + r)
-        loader = get_dataloader(W.shard(mols, r), tok, batch_size=W.PER_RANK, shuffle=False, num_workers=0)
-        batches.append([to_device(b, 'cuda') for b in loader])
+    batches, valid = zip(*[W.resident_batches(tok, r, 'cuda') for r in range(2)])
     model = W.build_model(tok)
     opt = model.configure_optimizers()
-    opt.set_epoch(0)
-    gens = [torch.Generator(device='cuda').manual_seed(100 + r) for r in range(2)]
-    for k in range(W.STEPS):
-        total = batches[0][k]['_native'].denoms + batches[1][k]['_native'].denoms
-        opt.zero_grad()
-        for r in range(2):
-            batches[r][k]['_native'].denoms.copy_(total)
-            eps = torch.randn(W.PER_RANK, 56, dtype=torch.float32, device='cuda', generator=gens[r])
-            model.training_step(batches[r][k], eps=eps).backward()      # the second backward accumulates
-        opt.step()
-        model.global_step += 1
+    draw = 0
+    for epoch in range(W.EPOCHS):
+        opt.set_epoch(epoch)
+        for k in range(W.STEPS):
+            total = batches[0][k]['_native'].local_denoms + batches[1][k]['_native'].local_denoms
+            opt.zero_grad()
+            for r in range(2):
+                batches[r][k]['_native'].denoms.copy_(total)
+                model.eps_draws = draw
+                eps = model.draw_eps(W.PER_RANK, r * W.PER_RANK)
+                model.training_step(batches[r][k], eps=eps).backward()      # the second backward accumulates
+            opt.step()
+            model.global_step += 1
+            draw += 1
+        draw += len(valid[0])          # every validation batch of a rank takes one draw as well
     want = model.flat_buffers()[0].detach().cpu()
     err = (got[0]['params'] - want).abs().max().item()
-    assert err <= 1e-6, f'two-rank fit differs from the undivided steps by {err:.3e}'
+    assert err <= 2e-6, f'two-rank fit differs from the undivided steps by {err:.3e}'
+    # the sampled latent of the two ranks' first batches = the sample one process draws for the 32 graphs together
+    for r in range(2):
+        model.eps_draws = draw          # every draw advances the counter
+        z = model.get_z(batches[r][0], eps=model.draw_eps(W.PER_RANK, r * W.PER_RANK))
+        assert torch.allclose(z.cpu(), got[r]['z'], rtol=1e-5, atol=1e-6), f'sampled z of rank {r}'
+    model.eps_draws = draw
+    both = model.draw_eps(2 * W.PER_RANK, 0)
+    model.eps_draws = draw
+    assert torch.equal(both[W.PER_RANK:], model.draw_eps(W.PER_RANK, W.PER_RANK)), 'epsilon rows depend on the global index only'
