@@ -40,7 +40,8 @@ enum {
     PSVAE_E_SHAPE = -2,     /* a size is negative / inconsistent / unsupported */
     PSVAE_E_ALIGN = -3,     /* pointer or leading dimension breaks an alignment rule */
     PSVAE_E_WORKSPACE = -4, /* workspace too small (see psvae_workspace_bytes) */
-    PSVAE_E_CAPACITY = -5   /* host output buffer too small */
+    PSVAE_E_CAPACITY = -5,  /* host output buffer too small */
+    PSVAE_E_STATIC_LIMIT = -6 /* problem needs more scratch than the no-allocation entry point's static array holds */
 };
 
 const char* psvae_strerror(int code);
@@ -264,6 +265,18 @@ int psvae_linear_backward_weight(const float* dy, int lddy, int64_t seg_stride_d
                                  int64_t seg_stride_x, int nseg, float* dw, float* db, int M, int N, int K,
                                  void* scratch, size_t scratch_bytes, void* stream);
 size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg);
+/* psvae_linear_backward_weight without a scratch argument and without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  The slab partial sums of the split reduction go to a static device
+ * array of psvae_noalloc_scratch_bytes() = 16 MiB that every GPU the library runs on holds until the process
+ * ends; a problem whose planned split needs more (nseg * splits * N * (K+1) floats) is refused with
+ * PSVAE_E_STATIC_LIMIT.  Same kernels and same results, bit for bit, as psvae_linear_backward_weight given a
+ * scratch buffer of psvae_linear_scratch_bytes.  All calls on one GPU share the array: calls that overlap there
+ * (two streams, two host threads) race; calls on one stream do not. */
+size_t psvae_noalloc_scratch_bytes(void);
+int psvae_linear_backward_weight_noalloc(const float* dy, int lddy, int64_t seg_stride_dy, const float* x, int ldx,
+                                         int64_t seg_stride_x, int nseg, float* dw, float* db, int M, int N, int K,
+                                         void* stream);
 /* GINEConv message + aggregation (torch_geometric GINEConv as used at src/modules/encoder.py:48,58):
  * out[i] = (1+eps) x[i] + sum_{e in row i} relu(x[col[e]] + edge_w[:,etype[e]] + edge_b) */
 int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col,

@@ -124,6 +124,9 @@ def lib():
     L.psvae_linear_backward_input.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.psvae_linear_backward_weight.argtypes = [vp, C.c_int, i64, vp, C.c_int, i64, C.c_int, vp, vp, C.c_int, C.c_int,
                                                C.c_int, vp, sz, vp]
+    L.psvae_noalloc_scratch_bytes.restype = sz
+    L.psvae_linear_backward_weight_noalloc.argtypes = [vp, C.c_int, i64, vp, C.c_int, i64, C.c_int, vp, vp, C.c_int, C.c_int,
+                                                       C.c_int, vp]
     L.psvae_gine_aggregate_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]
     L.psvae_gine_aggregate_backward.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, vp, vp,
                                                 C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
@@ -167,6 +170,7 @@ EXPORTS = (
     'psvae_step_backward', 'psvae_step_backward_signal', 'psvae_streams_init', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
     'psvae_score_links', 'psvae_normal_rows', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
+    'psvae_noalloc_scratch_bytes', 'psvae_linear_backward_weight_noalloc',
     'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',
     'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs', 'psvae_gather_molecules',

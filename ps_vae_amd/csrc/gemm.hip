@@ -15,6 +15,7 @@
 // keeps ~2 x 16 MFMAs of work between a load's issue and its first use.
 #include "psvae_internal.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -591,4 +592,53 @@ int linear_bwd_w(hipStream_t s, const float* dy, int lddy, int64_t seg_dy, const
     d.nseg = nseg; d.seg_a = seg_dy; d.seg_b = seg_x; d.sum_segments = true;
     d.scratch = scratch; d.scratch_floats = scratch_floats;
     return gemm_f32(s, d);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient without any allocation: the slab partial sums of the split reduction live in a file-scope device
+// array instead of a caller-supplied scratch buffer, for callers that cannot allocate (HIP graph capture, serving
+// loops, harnesses that forbid hipMalloc).  Every GPU the library runs on holds its own copy of the array (16 MiB)
+// until the process ends.  In host code the array's NAME is only a stand-in: the device address is asked for once
+// per device with hipGetSymbolAddress and kept; kernels are given that address.
+namespace {
+constexpr size_t NOALLOC_SCRATCH_FLOATS = (size_t)4 << 20;       // 16 MiB
+__device__ __align__(256) float scratch[NOALLOC_SCRATCH_FLOATS];
+float* noalloc_ptr[64] = {};
+std::mutex noalloc_mu;
+
+int noalloc_scratch(float** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return PSVAE_E_SHAPE;
+    std::lock_guard<std::mutex> lock(noalloc_mu);
+    if (!noalloc_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));        // this device's copy (the current device's)
+        if (e != hipSuccess) return (int)e;
+        if (!p) return PSVAE_E_NULL;
+        noalloc_ptr[dev] = (float*)p;
+    }
+    *out = noalloc_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t psvae_noalloc_scratch_bytes(void) { return NOALLOC_SCRATCH_FLOATS * sizeof(float); }
+
+extern "C" int psvae_linear_backward_weight_noalloc(const float* dy, int lddy, int64_t seg_stride_dy, const float* x, int ldx,
+                                                    int64_t seg_stride_x, int nseg, float* dw, float* db, int M, int N, int K,
+                                                    void* stream) {
+    if (!dy || !x || !dw) return PSVAE_E_NULL;
+    if (M < 0 || N < 1 || K < 1 || nseg < 1 || lddy < N || ldx < K) return PSVAE_E_SHAPE;
+    // what the planned split needs (same plan as psvae_linear_backward_weight with a scratch buffer of
+    // psvae_linear_scratch_bytes): beyond the static array's size the call is refused, never degraded
+    const size_t need = gemm_scratch_floats(N, db ? K + 1 : K, M, nseg, true);
+    if (need > NOALLOC_SCRATCH_FLOATS) return PSVAE_E_STATIC_LIMIT;
+    float* ptr = nullptr;
+    PSVAE_TRY(noalloc_scratch(&ptr));
+    // nothing in the array has to start at zero: every slab element the reduction reads is written by this call's
+    // product kernel first.  Calls that overlap on one GPU (two streams, two threads) share the array and race.
+    return linear_bwd_w((hipStream_t)stream, dy, lddy, seg_stride_dy, x, ldx, seg_stride_x, nseg, dw, db, M, N, K, ptr,
+                        NOALLOC_SCRATCH_FLOATS);
 }
