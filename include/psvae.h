@@ -282,6 +282,34 @@ int psvae_linear_backward_weight_noalloc(const float* dy, int lddy, int64_t seg_
 int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
                                  const int32_t* etype, const float* edge_w, const float* edge_b, float one_plus_eps,
                                  float* out, int ldo, int n, int H, void* stream);
+/* One whole GINE application (src/modules/encoder.py:57-59: `x = self.conv(x, edge_index, edge_attr)` with the
+ * two-layer MLP of src/modules/common_nn.py:8-23) in ONE launch:
+ *   agg = the aggregation above;  hid = relu(agg w1^T + b1);  y = hid w2^T + b2      (w1, w2 [H,H] row-major)
+ * The aggregated rows are built straight into the first product's operand image in LDS and the hidden rows stay
+ * there for the second product: neither is read back from memory.  agg and hid ([n,H] each, both or neither)
+ * receive copies for a backward pass; NULL = inference.  H a multiple of 4, 16 <= H <= 512, ldx % 4 == 0.
+ * `scratch` (psvae_gine_layer_scratch_bytes(H) bytes, 16-byte aligned) receives the two weight matrices re-laid
+ * for the matrix cores' operand fragments (the whole-step entry points do that once per step). */
+size_t psvae_gine_layer_scratch_bytes(int H);
+int psvae_gine_layer_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
+                             const float* edge_w, const float* edge_b, float one_plus_eps, const float* w1,
+                             const float* b1, const float* w2, const float* b2, float* agg, float* hid, float* y,
+                             int ldy, int n, int H, void* scratch, size_t scratch_bytes, void* stream);
+/* The link scorer's forward pass (src/modules/vae_piece_decoder.py:97-117) in ONE launch: for each of the S selected
+ * pairs, pair_in = [emb[src] | emb[dst] | z[graph]] (P = 2H + Z columns), h1 = relu(pair_in w0^T + b0),
+ * h2 = relu(h1 w1^T + b1), h3 = h2 w2^T + b2 (the MLP(P, P/2, P, ReLU, 3) of :36-45), logits = h3 w3^T + b3 (4 bond
+ * classes), lse = logsumexp(logits), row_loss = lse - logits[gold] (the rows of the edge cross-entropy, :53,117).
+ * The pair rows are gathered straight into LDS and the activations stay there between the layers; pair_in [S,P],
+ * h1/h2 [S,P/2], h3 [S,P], logits [S,4], row_loss/lse [S] receive the copies a backward pass reads.  Supported for
+ * 320 < P/2 <= 384 (H = 300, Z = 56 gives 328), H % 4 == Z % 4 == lde % 4 == 0; scratch: psvae_scorer_scratch_bytes
+ * (0 = unsupported size) bytes, 16-byte aligned, for the re-laid weights. */
+size_t psvae_scorer_scratch_bytes(int H, int Z);
+int psvae_scorer_forward(const float* emb, int lde, const float* z, const int32_t* pair_src, const int32_t* pair_dst,
+                         const int32_t* pair_graph, const int32_t* pair_gold, const float* w0, const float* b0,
+                         const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                         const float* b3, float* pair_in, float* h1, float* h2, float* h3, float* logits,
+                         float* row_loss, float* lse, int S, int H, int Z, void* scratch, size_t scratch_bytes,
+                         void* stream);
 /* dx[j] = (1+eps) da[j] + sum_{e in rowT j} da[colT[e]] * (x[j] + edge(etypeT[e]) > 0)  (+ pooled-gradient broadcast).
  * The same products summed per bond type are the gradient of edge_trans: when d_edge_w [H,4] is given the call
  * also writes it and d_edge_b [H], using `partial`, scratch of psvae_gine_edge_grad_scratch(n, H) floats. */

@@ -128,6 +128,12 @@ def lib():
     L.psvae_linear_backward_weight_noalloc.argtypes = [vp, C.c_int, i64, vp, C.c_int, i64, C.c_int, vp, vp, C.c_int, C.c_int,
                                                        C.c_int, vp]
     L.psvae_gine_aggregate_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.psvae_gine_layer_scratch_bytes.restype = sz
+    L.psvae_gine_layer_scratch_bytes.argtypes = [C.c_int]
+    L.psvae_gine_layer_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, vp]
+    L.psvae_scorer_scratch_bytes.restype = sz
+    L.psvae_scorer_scratch_bytes.argtypes = [C.c_int, C.c_int]
+    L.psvae_scorer_forward.argtypes = [vp, C.c_int] + [vp] * 20 + [C.c_int] * 3 + [vp, sz, vp]
     L.psvae_gine_aggregate_backward.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, C.c_int, vp, vp,
                                                 C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.psvae_gine_edge_grad_scratch.restype = sz
@@ -171,7 +177,7 @@ EXPORTS = (
     'psvae_score_links', 'psvae_normal_rows', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
     'psvae_noalloc_scratch_bytes', 'psvae_linear_backward_weight_noalloc',
-    'psvae_gine_aggregate_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
+    'psvae_gine_aggregate_forward', 'psvae_scorer_scratch_bytes', 'psvae_scorer_forward', 'psvae_gine_layer_scratch_bytes', 'psvae_gine_layer_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',
     'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs', 'psvae_gather_molecules',
     'psvae_pack_bound', 'psvae_pack_batch', 'psvae_collate_device_layout', 'psvae_collate_device_scratch_bytes',

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpsvae_hip.so')
-SOURCES = ['gemm.hip', 'graph_kernels.hip', 'head_kernels.hip', 'gru.hip', 'step.hip', 'inference.hip', 'collate_device.hip', 'capi.hip', 'profiler.hip', 'rng.hip', 'collate.cpp']
+SOURCES = ['gemm.hip', 'fused_layer.hip', 'graph_kernels.hip', 'head_kernels.hip', 'gru.hip', 'step.hip', 'inference.hip', 'collate_device.hip', 'capi.hip', 'profiler.hip', 'rng.hip', 'collate.cpp']
 HEADERS = ['psvae_internal.h', os.path.join('..', '..', 'include', 'psvae.h')]
 
 

@@ -66,6 +66,50 @@ extern "C" int psvae_gine_aggregate_forward(const float* x, int ldx, const int32
     return gine_agg_fwd((hipStream_t)stream, &g, 1, ldx, ldo, n, H);
 }
 
+extern "C" size_t psvae_gine_layer_scratch_bytes(int H) { return 2 * fused_pack_floats(H, H) * sizeof(float); }
+
+extern "C" int psvae_gine_layer_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col,
+                                        const int32_t* etype, const float* edge_w, const float* edge_b, float one_plus_eps,
+                                        const float* w1, const float* b1, const float* w2, const float* b2, float* agg,
+                                        float* hid, float* y, int ldy, int n, int H, void* scratch, size_t scratch_bytes,
+                                        void* stream) {
+    if (!x || !rowptr || !edge_w || !edge_b || !w1 || !b1 || !w2 || !b2 || !y || !scratch) return PSVAE_E_NULL;
+    if ((agg == nullptr) != (hid == nullptr)) return PSVAE_E_NULL;
+    if (n < 0 || H < 4 || ldx < H || ldy < H) return PSVAE_E_SHAPE;
+    if (!gine_layer_fused_supported(H, ldx, ldy)) return PSVAE_E_SHAPE;
+    if (!aligned16(scratch)) return PSVAE_E_ALIGN;
+    if (scratch_bytes < psvae_gine_layer_scratch_bytes(H)) return PSVAE_E_WORKSPACE;
+    float* w1p = (float*)scratch;
+    float* w2p = w1p + fused_pack_floats(H, H);
+    const FusedPack pk[2] = {{w1, w1p, H, H, H, false}, {w2, w2p, H, H, H, false}};
+    PSVAE_TRY(fused_pack((hipStream_t)stream, pk, 2));
+    FusedLayerGroup g{x, rowptr, col ? col : rowptr, etype ? etype : rowptr, edge_w, edge_b, w1p, b1, w2p, b2, agg, hid, y,
+                      one_plus_eps, 0};
+    return gine_layer_fwd((hipStream_t)stream, &g, 1, ldx, ldy, n, H, agg != nullptr);
+}
+
+extern "C" size_t psvae_scorer_scratch_bytes(int H, int Z) {
+    if (!scorer_fused_supported(H, Z, H)) return 0;
+    return scorer_pack_floats(H, Z) * sizeof(float);
+}
+
+extern "C" int psvae_scorer_forward(const float* emb, int lde, const float* z, const int32_t* pair_src, const int32_t* pair_dst,
+                                    const int32_t* pair_graph, const int32_t* pair_gold, const float* w0, const float* b0,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                    const float* b3, float* pair_in, float* h1, float* h2, float* h3, float* logits,
+                                    float* row_loss, float* lse, int S, int H, int Z, void* scratch, size_t scratch_bytes,
+                                    void* stream) {
+    if (!w0 || !w1 || !w2 || !scratch) return PSVAE_E_NULL;
+    if (S < 0 || lde < H) return PSVAE_E_SHAPE;
+    if (!scorer_fused_supported(H, Z, lde)) return PSVAE_E_SHAPE;
+    if (!aligned16(scratch)) return PSVAE_E_ALIGN;
+    if (scratch_bytes < psvae_scorer_scratch_bytes(H, Z)) return PSVAE_E_WORKSPACE;
+    PSVAE_TRY(scorer_pack((hipStream_t)stream, w0, w1, w2, (float*)scratch, H, Z));
+    ScorerFwd f{emb, lde, z, pair_src, pair_dst, pair_graph, pair_gold, (const float*)scratch, b0, b1, b2, w3, b3,
+                pair_in, h1, h2, h3, logits, row_loss, lse, S, H, Z};
+    return scorer_fwd_fused((hipStream_t)stream, f);
+}
+
 extern "C" size_t psvae_gine_edge_grad_scratch(int n, int H) {
     if (n < 0 || H < 4 || H % 4) return 0;
     return ((size_t)gine_agg_bwd_blocks(n, H) + ETAB_SEGMENTS) * 4 * H;

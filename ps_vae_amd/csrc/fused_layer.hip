@@ -1,0 +1,549 @@
+// One GINE application as ONE launch (src/modules/encoder.py:57-59 with torch_geometric's GINEConv and the
+// two-layer MLP of src/modules/common_nn.py:8-23):
+//     agg_i = (1+eps) x_i + sum_{e: dst=i} relu(x_src(e) + edge(type_e))        message + CSR segment-sum
+//     hid   = relu(agg W1^T + b1)                                                Linear + ReLU
+//     y     = hid W2^T + b2                                                      Linear
+// A workgroup owns 32 consecutive nodes.  It builds their aggregated rows straight into an LDS image [32][K]
+// (the A operand of the first product; also streamed to memory when backward needs it), multiplies the image with
+// W1, writes the activated result back into the same LDS image, multiplies that with W2 and stores the rows of y.
+// Neither agg nor hid is ever read back from memory by the forward pass.
+//
+// The products run on v_mfma_f32_16x16x4_f32 (exact fp32).  The A operand stays in LDS for the whole reduction; the
+// B operand (the weights) goes from L2 straight into registers, from a PACKED copy that pack_weights() writes
+// once per step: Wp[kb][q][c][j] = W[c][16 kb + 4 q + j] (zero beyond the matrix), so that lane (column c = l & 15,
+// quarter q = l >> 4) fetches ONE float4 whose element j feeds the j-th MFMA of the block (the A operand takes the
+// same k: one ds_read_b128 of the image row), and the 16 lanes of a quarter read 256 contiguous bytes.  (Read from
+// the row-major matrix, the same fragment is 64 separate 16-byte requests per instruction, 16 rows apart, and the
+// address path, not the matrix pipe, sets the pace: 40-55 % MFMA utilisation measured.)  A block of 16 reduction
+// indices costs a wave 2 LDS reads and CT global loads for 8 CT MFMAs.  Nothing is staged cooperatively, hence no
+// barrier inside a product: the four waves (each owning CT 16-column tiles of all 32 rows) run independently, with
+// the weights prefetched two blocks ahead.  Image pitch = 8 mod 64 floats: conflict-free ds_read_b128 for this
+// lane map (rows two apart land on disjoint 16-byte bank slots inside every 16-lane service group).
+#include "psvae_internal.h"
+#include <algorithm>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int FL_ROWS = 32, FL_RT = 2, FL_NB = 8, FL_THREADS = 256;
+
+__device__ __forceinline__ float4 fl_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Packed weights: [KB][4][Npad][4] floats, KB = ceil(K / 16) blocks, Npad = 64 CT columns (CT 16-column tiles for
+// each of the four waves).  `transposed`: the source holds W^T ([K][N] row-major, i.e. the product is x W instead
+// of x W^T: the input-gradient form).
+struct PackOne { const float* src; float* dst; int N, K, ld, transposed, Npad, KB; };
+struct PackArgs { PackOne m[8]; int count; };
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+    const PackOne& m = a.m[blockIdx.y];
+    const int total = m.KB * 4 * m.Npad;           // float4 slots
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int c = t % m.Npad, kbq = t / m.Npad, k = kbq * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = c < m.N && k + j < m.K;
+            const size_t idx = m.transposed ? (size_t)min(k + j, m.K - 1) * m.ld + min(c, m.N - 1)
+                                            : (size_t)min(c, m.N - 1) * m.ld + min(k + j, m.K - 1);
+            const float x = m.src[idx];
+            v[j] = ok ? x : 0.f;
+        }
+        *reinterpret_cast<float4*>(m.dst + (size_t)t * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// acc[rt][ct] += img[rows of tile rt][0 .. 16 KB) . W[columns of tile ct][same k], W packed as above.  RT 16-row
+// tiles per workgroup (image rows rt * 16 + (l & 15)), CT 16-column tiles per wave.
+template <int CT, int RT>
+__device__ __forceinline__ void fl_product(const float* img, int P, const float* __restrict__ Wp, int KB, int rot, int wave,
+                                           int lane, floatx4 (&acc)[RT][CT]) {
+    // Every workgroup of a launch streams the SAME packed matrix; started together and walking it in the same order
+    // they would all ask the same few L2 channels for the same lines at the same moment (measured: 4-5 TB/s over
+    // the whole GPU, the matrix cores a quarter to half busy).  So each workgroup starts its walk `rot` blocks
+    // into the reduction and wraps around: at any moment the workgroups read different parts of the matrix.
+    const int nl = lane & 15, kq = lane >> 4;
+    const int kb0 = rot % KB;
+    constexpr int Npad = 64 * CT;
+    const float* wlane = Wp + ((size_t)kq * Npad + wave * CT * 16 + nl) * 4;      // + kb * 16 * Npad + ct * 64
+    const float* arow = img + nl * P + 4 * kq;                                      // + rt * 16 * P + kb * 16
+    float4 b0[CT], b1[CT], b2[CT], a0[RT], a1[RT], a2[RT];
+    // blocks past the last one are clamped to it (fetched, never used)
+#define FL_LOADB(B_, KB_)                                                                          \
+    {                                                                                              \
+        int kbr_ = min((KB_), KB - 1) + kb0;                                                       \
+        kbr_ -= kbr_ >= KB ? KB : 0;                                                               \
+        const float* p_ = wlane + (size_t)kbr_ * (16 * Npad);                                      \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) B_[ct] = fl_ld4(p_ + ct * 64);           \
+    }
+#define FL_READA(A_, KB_)                                                                                   \
+    {                                                                                                       \
+        int kbr_ = min((KB_), KB - 1) + kb0;                                                                \
+        kbr_ -= kbr_ >= KB ? KB : 0;                                                                        \
+        const int o_ = kbr_ * 16;                                                                           \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                   \
+            A_[rt] = *reinterpret_cast<const float4*>(arow + rt * 16 * P + o_);                             \
+    }
+#define FL_MFMA(A_, B_)                                                                                         \
+    {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
+                const float bv = j == 0 ? B_[ct].x : (j == 1 ? B_[ct].y : (j == 2 ? B_[ct].z : B_[ct].w));      \
+                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                             \
+                    const float av = j == 0 ? A_[rt].x : (j == 1 ? A_[rt].y : (j == 2 ? A_[rt].z : A_[rt].w));  \
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[rt][ct], 0, 0, 0);           \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // Stage s (registers a_s, b_s) holds block kb = s (mod 3).  Every block's weights are requested two blocks
+    // ahead and its image rows one block ahead; the scheduling barriers keep the requests in program order, so that
+    // each wait is for the oldest outstanding group only.
+    FL_LOADB(b0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    FL_LOADB(b1, 1)
+    FL_READA(a0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb = 0; kb < KB; kb += 3) {        // (the guards are uniform and hold no loads)
+        FL_LOADB(b2, kb + 2)
+        FL_READA(a1, kb + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        FL_MFMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        FL_LOADB(b0, kb + 3)
+        FL_READA(a2, kb + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < KB) FL_MFMA(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        FL_LOADB(b1, kb + 4)
+        FL_READA(a0, kb + 3)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < KB) FL_MFMA(a2, b2)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FL_READA
+#undef FL_MFMA
+#undef FL_LOADB
+}
+
+template <int CT, int RT>
+__device__ __forceinline__ void fl_zero(floatx4 (&acc)[RT][CT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+}
+
+// What a product leaves in the accumulators, plus bias (and ReLU), written to columns col0 + c of an LDS image
+// and/or of global rows row0 + r (< nrows).  An accumulator holds rows 4 (l >> 4) + i, column l & 15 of its tile.
+// ZERO_PAD: image columns from N up to the wave tiles' end are written as zeros (they are the next product's
+// reduction padding); otherwise columns >= N are left alone.
+template <int CT, int RT, bool RELU, bool ZERO_PAD>
+__device__ __forceinline__ void fl_store(const floatx4 (&acc)[RT][CT], const float (&bias)[CT], int N, float* img, int P, int col0,
+                                         float* gout, size_t ldg, int row0, int nrows, int wave, int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = (wave * CT + ct) * 16 + nl;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rt * 16 + 4 * kq + i;
+                float v = acc[rt][ct][i] + bias[ct];
+                if (RELU) v = fmaxf(v, 0.f);
+                if (c >= N) v = 0.f;
+                if (img && (c < N || (ZERO_PAD && col0 + c < P))) img[r * P + col0 + c] = v;
+                if (gout && c < N && row0 + r < nrows) gout[(size_t)(row0 + r) * ldg + col0 + c] = v;
+            }
+    }
+}
+
+template <int CT>
+__device__ __forceinline__ void fl_bias(const float* __restrict__ b, int N, int wave, int lane, float (&out)[CT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) out[ct] = b[min((wave * CT + ct) * 16 + (lane & 15), N - 1)];
+}
+
+struct FLGroup {
+    const float* x;                               // layer input [n, ldx]
+    const int32_t *rowptr, *col, *etype;          // CSR by target, sources in edge order
+    const float *edge_w, *edge_b;                 // edge_trans [H,4], [H]
+    const float *w1p, *b1, *w2p, *b2;             // conv.nn.seq.{0,2}: packed weights, biases
+    float *agg, *hid;                             // [n, H] each, saved for backward; may be null
+    float* y;                                     // [n, ldy]
+    float ope;
+};
+struct FLArgs { FLGroup g[2]; int n, H, P, ldx, ldy; };
+
+// SAVE: agg and hid are also written to memory (training); without it nothing but y leaves the workgroup.
+template <int CT, bool SAVE>
+__global__ __launch_bounds__(FL_THREADS) void gine_layer_fwd_kernel(const FLArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    __shared__ int s_e0[FL_ROWS], s_deg[FL_ROWS], s_nb[FL_ROWS][FL_NB], s_ty[FL_ROWS][FL_NB];
+    const FLGroup& g = a.g[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, P = a.P, H4 = H >> 2, n = a.n, KB = (H + 15) >> 4;
+    float* img = fl_lds;                   // [32][P]
+    float* etab = fl_lds + FL_ROWS * P;    // [5][H]: edge term per bond type, row 4 = -inf ("no edge")
+    // workgroups go to the 8 XCDs round-robin: neighbouring row tiles (which share neighbour rows) are renumbered
+    // onto one XCD so that a row is fetched into one L2
+    const int per_xcd = gridDim.x / 8, bx = blockIdx.x;
+    const int tile = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
+    const int row0 = tile * FL_ROWS;
+    const float* __restrict__ x = g.x;
+    // the biases of this lane's columns, requested now (used after the products)
+    float bias1[CT], bias2[CT];
+    fl_bias<CT>(g.b1, H, wave, lane, bias1);
+    fl_bias<CT>(g.b2, H, wave, lane, bias2);
+
+    // ---- phase 1: the tile's CSR rows (one thread per node), then the edge table, then the aggregation
+    if (tid < FL_ROWS) {
+        const int i = min(row0 + tid, n - 1);
+        const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+        const int deg = row0 + tid < n ? e1 - e0 : 0;
+        s_e0[tid] = e0; s_deg[tid] = deg;
+        const int E = g.rowptr[n], emax = max(E - 1, 0);
+        const int32_t* __restrict__ colp = E > 0 ? g.col : g.rowptr;        // a batch without edges: any readable words
+        const int32_t* __restrict__ typ = E > 0 ? g.etype : g.rowptr;
+#pragma unroll
+        for (int k = 0; k < FL_NB; ++k) {
+            const int e = min(e0 + k, emax);
+            const int j = colp[e], t = typ[e] & 3;
+            s_nb[tid][k] = k < deg ? j : i;         // surplus slots: own row (a valid address), type 4 => message 0
+            s_ty[tid][k] = k < deg ? t : 4;
+        }
+    }
+    for (int k = tid; k < H; k += FL_THREADS) {
+        const float4 wk = fl_ld4(g.edge_w + (size_t)k * 4);
+        const float bk = g.edge_b[k];
+        etab[k] = wk.x + bk; etab[H + k] = wk.y + bk; etab[2 * H + k] = wk.z + bk; etab[3 * H + k] = wk.w + bk;
+        etab[4 * H + k] = -INFINITY;
+    }
+    {   // columns H .. (pitch) of the image read as zeros in the products
+        const int padw = P - H;
+        for (int k = tid; k < FL_ROWS * padw; k += FL_THREADS) img[(k / padw) * P + H + (k % padw)] = 0.f;
+    }
+    __syncthreads();
+    {
+        const int items = FL_ROWS * H4;
+        // two items per round: 2 x (own row + 4 neighbour rows) = 10 independent 16-byte loads in flight per thread
+        for (int it = tid; it < items; it += 2 * FL_THREADS) {
+            float4 acc2[2], own2[2];
+            int r2[2], c2[2];
+            float4 xs[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / H4, c = (t - r * H4) * 4;
+                r2[u] = r; c2[u] = c;
+                const int i = min(row0 + r, n - 1);
+                own2[u] = fl_ld4(x + (size_t)i * a.ldx + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xs[u][k] = fl_ld4(x + (size_t)s_nb[r][k] * a.ldx + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = r2[u], c = c2[u];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 e = *reinterpret_cast<const float4*>(etab + s_ty[r][k] * H + c);
+                    acc.x += fmaxf(xs[u][k].x + e.x, 0.f); acc.y += fmaxf(xs[u][k].y + e.y, 0.f);
+                    acc.z += fmaxf(xs[u][k].z + e.z, 0.f); acc.w += fmaxf(xs[u][k].w + e.w, 0.f);
+                }
+                const int deg = s_deg[r];
+                for (int k = 4; k < deg; ++k) {          // the rare node with more than four bonds, in edge order
+                    int j, t;
+                    if (k < FL_NB) { j = s_nb[r][k]; t = s_ty[r][k]; }
+                    else { const int e = s_e0[r] + k; j = g.col[e]; t = g.etype[e] & 3; }
+                    const float4 xv = fl_ld4(x + (size_t)j * a.ldx + c);
+                    const float4 e = *reinterpret_cast<const float4*>(etab + t * H + c);
+                    acc.x += fmaxf(xv.x + e.x, 0.f); acc.y += fmaxf(xv.y + e.y, 0.f);
+                    acc.z += fmaxf(xv.z + e.z, 0.f); acc.w += fmaxf(xv.w + e.w, 0.f);
+                }
+                acc2[u] = make_float4(acc.x + g.ope * own2[u].x, acc.y + g.ope * own2[u].y, acc.z + g.ope * own2[u].z,
+                                      acc.w + g.ope * own2[u].w);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (it + u * FL_THREADS >= items) continue;
+                const int r = r2[u], c = c2[u];
+                const bool live = row0 + r < n;
+                const float4 v = live ? acc2[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(img + r * P + c) = v;
+                if (SAVE && live) *reinterpret_cast<float4*>(g.agg + (size_t)(row0 + r) * H + c) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: hid = relu(agg W1^T + b1), back into the image
+    floatx4 acc[FL_RT][CT];
+    fl_zero<CT, FL_RT>(acc);
+    fl_product<CT, FL_RT>(img, P, g.w1p, KB, tile * 5, wave, lane, acc);
+    __syncthreads();            // every wave is done reading the aggregated image
+    fl_store<CT, FL_RT, true, true>(acc, bias1, H, img, P, 0, SAVE ? g.hid : nullptr, H, row0, n, wave, lane);
+    __syncthreads();
+
+    // ---- phase 3: y = hid W2^T + b2
+    fl_zero<CT, FL_RT>(acc);
+    fl_product<CT, FL_RT>(img, P, g.w2p, KB, tile * 5 + 9, wave, lane, acc);
+    fl_store<CT, FL_RT, false, false>(acc, bias2, H, nullptr, 0, 0, g.y, a.ldy, row0, n, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The link scorer's forward pass as ONE launch (src/modules/vae_piece_decoder.py:97-117):
+//     pin  = [emb[src] | emb[dst] | z[graph]]                        pair input, gathered straight into LDS
+//     s1   = relu(pin W0^T + b0);  s2 = relu(s1 W1^T + b1);  s3 = s2 W2^T + b2      MLP(P, P/2, P, ReLU, 3)
+//     logits = s3 W3^T + b3  (4 bond classes), lse, row loss = lse - logits[gold]   Linear + cross-entropy rows
+// A workgroup owns 16 consecutive pairs; the activations move between two LDS images and are copied to memory
+// only for backward's use.  The last MLP layer (P outputs) runs as two halves of P/2 columns over the same image.
+struct ScorerArgs {
+    const float* emb; int lde;                 // decoder-side node embeddings [n, lde]
+    const float* z;                            // [B, Z]
+    const int32_t *src, *dst, *graph, *gold;   // [S]
+    const float *w0p, *b0, *w1p, *b1, *w2p_lo, *w2p_hi, *b2, *w3, *b3;
+    float *pin, *s1, *s2, *s3, *logits, *row_loss, *lse;
+    int S, H, Z, P, P2, PA, PB;
+};
+
+template <int CT>
+__global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    __shared__ int s_src[16], s_dst[16], s_gr[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 16, S = a.S, H = a.H, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
+    float* imgA = fl_lds;              // [16][PA]: pair input, later s3
+    float* imgB = fl_lds + 16 * PA;    // [16][PB]: s1, then s2
+    float bias0[CT], bias1[CT], bias2lo[CT], bias2hi[CT];
+    fl_bias<CT>(a.b0, P2, wave, lane, bias0);
+    fl_bias<CT>(a.b1, P2, wave, lane, bias1);
+    fl_bias<CT>(a.b2, P2, wave, lane, bias2lo);
+    fl_bias<CT>(a.b2 + P2, P2, wave, lane, bias2hi);
+    if (tid < 16) {
+        const int sidx = min(row0 + tid, S - 1);
+        s_src[tid] = a.src[sidx]; s_dst[tid] = a.dst[sidx]; s_gr[tid] = a.graph[sidx];
+    }
+    for (int k = tid; k < 16 * (PA - P); k += FL_THREADS) imgA[(k / (PA - P)) * PA + P + k % (PA - P)] = 0.f;
+    for (int k = tid; k < 16 * (PB - P2); k += FL_THREADS) imgB[(k / (PB - P2)) * PB + P2 + k % (PB - P2)] = 0.f;
+    __syncthreads();
+    {   // gather: four chunks per thread and round, all loads first
+        const int P4 = P >> 2, items = 16 * P4;
+        for (int it = tid; it < items; it += 4 * FL_THREADS) {
+            float4 v[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / P4, c = (t - r * P4) * 4;
+                rr[u] = r; cc[u] = c;
+                const float* p = c < H ? a.emb + (size_t)s_src[r] * a.lde + c
+                                       : (c < 2 * H ? a.emb + (size_t)s_dst[r] * a.lde + (c - H) : a.z + (size_t)s_gr[r] * a.Z + (c - 2 * H));
+                v[u] = fl_ld4(p);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (it + u * FL_THREADS >= items) continue;
+                const bool live = row0 + rr[u] < S;
+                const float4 w = live ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(imgA + rr[u] * PA + cc[u]) = w;
+                if (live) *reinterpret_cast<float4*>(a.pin + (size_t)(row0 + rr[u]) * P + cc[u]) = w;
+            }
+        }
+    }
+    __syncthreads();
+    floatx4 acc[1][CT];
+    // s1
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgA, PA, a.w0p, (P + 15) >> 4, blockIdx.x * 7, wave, lane, acc);
+    fl_store<CT, 1, true, true>(acc, bias0, P2, imgB, PB, 0, a.s1, P2, row0, S, wave, lane);
+    __syncthreads();
+    // s2 (in place)
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgB, PB, a.w1p, (P2 + 15) >> 4, blockIdx.x * 5, wave, lane, acc);
+    __syncthreads();
+    fl_store<CT, 1, true, true>(acc, bias1, P2, imgB, PB, 0, a.s2, P2, row0, S, wave, lane);
+    __syncthreads();
+    // s3, two halves, into the first image (the pair input is no longer needed)
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgB, PB, a.w2p_lo, (P2 + 15) >> 4, blockIdx.x * 5 + 3, wave, lane, acc);
+    fl_store<CT, 1, false, false>(acc, bias2lo, P2, imgA, PA, 0, a.s3, P, row0, S, wave, lane);
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgB, PB, a.w2p_hi, (P2 + 15) >> 4, blockIdx.x * 5 + 11, wave, lane, acc);
+    fl_store<CT, 1, false, false>(acc, bias2hi, P2, imgA, PA, P2, a.s3, P, row0, S, wave, lane);
+    __syncthreads();
+    // head: wave w takes rows 4w .. 4w+3; lanes split the P columns in float4 chunks
+    {
+        const int P4 = P >> 2;
+        float part[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[i][c] = 0.f;
+        for (int ch = lane; ch < P4; ch += 64) {
+            float4 w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = fl_ld4(a.w3 + (size_t)c * P + ch * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 xv = *reinterpret_cast<const float4*>(imgA + (4 * wave + i) * PA + ch * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) part[i][c] += ((xv.x * w[c].x + xv.y * w[c].y) + xv.z * w[c].z) + xv.w * w[c].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part[i][c] += __shfl_xor(part[i][c], o, 64);
+        if (lane < 4) {
+            const int r = row0 + 4 * wave + lane;
+            if (r < S) {
+                float l[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // (static indexing: lane picks its row with selects)
+                    const float v = lane == 0 ? part[0][c] : (lane == 1 ? part[1][c] : (lane == 2 ? part[2][c] : part[3][c]));
+                    l[c] = v + a.b3[c];
+                }
+                const float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+                const float lse = mx + logf(((expf(l[0] - mx) + expf(l[1] - mx)) + expf(l[2] - mx)) + expf(l[3] - mx));
+                const int tg = a.gold[r];
+                reinterpret_cast<float4*>(a.logits)[r] = make_float4(l[0], l[1], l[2], l[3]);
+                a.lse[r] = lse;
+                a.row_loss[r] = lse - (tg == 0 ? l[0] : (tg == 1 ? l[1] : (tg == 2 ? l[2] : l[3])));
+            }
+        }
+    }
+}
+
+int fl_pitch(int K) {       // smallest pitch >= K rounded up to 16 with pitch = 8 mod 64
+    const int kp = (K + 15) / 16 * 16;
+    return (kp - 8 + 63) / 64 * 64 + 8;
+}
+
+}  // namespace
+
+static int fused_ct(int N) {          // the kernels' template value for N output columns: CT 16-column tiles per wave
+    const int ct = ((N + 15) / 16 + 3) / 4;
+    return ct <= 5 ? 5 : (ct <= 6 ? 6 : 8);
+}
+
+bool gine_layer_fused_supported(int H, int ldx, int ldy) {
+    return H % 4 == 0 && H >= 16 && H <= 512 && ldx % 4 == 0 && ldy >= H;
+}
+
+size_t fused_pack_floats(int N, int K) { return (size_t)((K + 15) / 16) * 16 * 64 * fused_ct(N); }
+
+int fused_pack(hipStream_t s, const FusedPack* d, int count) {
+    if (count < 1 || count > 8) return PSVAE_E_SHAPE;
+    PackArgs a{};
+    a.count = count;
+    int most = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!d[i].src || !d[i].dst) return PSVAE_E_NULL;
+        if (d[i].N < 1 || d[i].K < 1 || d[i].N > 512 || !aligned16(d[i].dst)) return PSVAE_E_SHAPE;
+        a.m[i] = PackOne{d[i].src, d[i].dst, d[i].N, d[i].K, d[i].ld, d[i].transposed ? 1 : 0, 64 * fused_ct(d[i].N), (d[i].K + 15) / 16};
+        most = std::max(most, a.m[i].KB * 4 * a.m[i].Npad);
+    }
+    ProfScope prof(s, KC_HEAD, 0);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((most + 255) / 256, count), dim3(256), 0, s, a);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int gine_layer_fwd(hipStream_t s, const FusedLayerGroup* grp, int ng, int ldx, int ldy, int n, int H, bool save) {
+    if (n <= 0) return 0;
+    if (ng < 1 || ng > 2) return PSVAE_E_SHAPE;
+    if (!gine_layer_fused_supported(H, ldx, ldy)) return PSVAE_E_SHAPE;
+    FLArgs a{};
+    double flops = 0;
+    for (int q = 0; q < ng; ++q) {
+        const FusedLayerGroup& f = grp[q];
+        if (!f.x || !f.rowptr || !f.col || !f.etype || !f.edge_w || !f.edge_b || !f.w1p || !f.b1 || !f.w2p || !f.b2 || !f.y)
+            return PSVAE_E_NULL;
+        if (save && (!f.agg || !f.hid)) return PSVAE_E_NULL;
+        if (!aligned16(f.x) || !aligned16(f.w1p) || !aligned16(f.w2p) || !aligned16(f.edge_w) || (save && !aligned16(f.agg)))
+            return PSVAE_E_ALIGN;
+        a.g[q] = FLGroup{f.x, f.rowptr, f.col, f.etype, f.edge_w, f.edge_b, f.w1p, f.b1, f.w2p, f.b2, f.agg, f.hid, f.y, f.ope};
+        flops += 4.0 * n * H * H;
+    }
+    a.n = n; a.H = H; a.P = fl_pitch(H); a.ldx = ldx; a.ldy = ldy;
+    const size_t lds = ((size_t)FL_ROWS * a.P + 5 * (size_t)H) * sizeof(float);
+    const int CT = fused_ct(H);
+    const dim3 grid((n + FL_ROWS - 1) / FL_ROWS, ng);
+    ProfScope prof(s, KC_GINE_LAYER, flops);
+#define FL_LAUNCH(CT_)                                                                                                   \
+    do {                                                                                                                 \
+        if (save) {                                                                                                      \
+            if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_fwd_kernel<CT_, true>,                    \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return (int)hipGetLastError();                                                                           \
+            hipLaunchKernelGGL((gine_layer_fwd_kernel<CT_, true>), grid, dim3(FL_THREADS), lds, s, a);                   \
+        } else {                                                                                                         \
+            if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_fwd_kernel<CT_, false>,                   \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return (int)hipGetLastError();                                                                           \
+            hipLaunchKernelGGL((gine_layer_fwd_kernel<CT_, false>), grid, dim3(FL_THREADS), lds, s, a);                  \
+        }                                                                                                                \
+    } while (0)
+    if (CT == 5) FL_LAUNCH(5);
+    else if (CT == 6) FL_LAUNCH(6);
+    else FL_LAUNCH(8);
+#undef FL_LAUNCH
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+bool scorer_fused_supported(int H, int Z, int lde) {
+    const int P = 2 * H + Z;
+    return H % 4 == 0 && Z % 4 == 0 && lde % 4 == 0 && P % 8 == 0 && P / 2 > 320 && P / 2 <= 384;
+}
+
+// packed-weight floats the fused scorer needs (w0, w1, two halves of w2), in that order
+size_t scorer_pack_floats(int H, int Z) {
+    const int P = 2 * H + Z, P2 = P / 2;
+    return fused_pack_floats(P2, P) + 3 * fused_pack_floats(P2, P2);
+}
+
+int scorer_pack(hipStream_t s, const float* w0, const float* w1, const float* w2, float* packed, int H, int Z) {
+    const int P = 2 * H + Z, P2 = P / 2;
+    float* w0p = packed;
+    float* w1p = w0p + fused_pack_floats(P2, P);
+    float* w2lo = w1p + fused_pack_floats(P2, P2);
+    float* w2hi = w2lo + fused_pack_floats(P2, P2);
+    const FusedPack pk[4] = {{w0, w0p, P2, P, P, false}, {w1, w1p, P2, P2, P2, false}, {w2, w2lo, P2, P2, P2, false},
+                             {w2 + (size_t)P2 * P2, w2hi, P2, P2, P2, false}};
+    return fused_pack(s, pk, 4);
+}
+
+int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
+    if (f.S <= 0) return 0;
+    if (!scorer_fused_supported(f.H, f.Z, f.lde)) return PSVAE_E_SHAPE;
+    const int P = 2 * f.H + f.Z, P2 = P / 2;
+    if (!f.emb || !f.z || !f.src || !f.dst || !f.graph || !f.gold || !f.packed || !f.b0 || !f.b1 || !f.b2 || !f.w3 || !f.b3 ||
+        !f.pin || !f.s1 || !f.s2 || !f.s3 || !f.logits || !f.row_loss || !f.lse) return PSVAE_E_NULL;
+    if (!aligned16(f.emb) || !aligned16(f.z) || !aligned16(f.packed) || !aligned16(f.w3) || !aligned16(f.pin) || !aligned16(f.logits))
+        return PSVAE_E_ALIGN;
+    ScorerArgs a{};
+    a.emb = f.emb; a.lde = f.lde; a.z = f.z; a.src = f.src; a.dst = f.dst; a.graph = f.graph; a.gold = f.gold;
+    a.w0p = f.packed; a.w1p = a.w0p + fused_pack_floats(P2, P); a.w2p_lo = a.w1p + fused_pack_floats(P2, P2);
+    a.w2p_hi = a.w2p_lo + fused_pack_floats(P2, P2);
+    a.b0 = f.b0; a.b1 = f.b1; a.b2 = f.b2; a.w3 = f.w3; a.b3 = f.b3;
+    a.pin = f.pin; a.s1 = f.s1; a.s2 = f.s2; a.s3 = f.s3; a.logits = f.logits; a.row_loss = f.row_loss; a.lse = f.lse;
+    a.S = f.S; a.H = f.H; a.Z = f.Z; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
+    const size_t lds = (size_t)16 * (a.PA + a.PB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)scorer_fwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return (int)hipGetLastError();
+        attr_set = true;
+    }
+    ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P + 4.0 * P));
+    hipLaunchKernelGGL(scorer_fwd_kernel<6>, dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}

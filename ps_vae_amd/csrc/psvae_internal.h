@@ -22,7 +22,7 @@ static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * 
 // ---------------------------------------------------------------- launch timer (profiler.hip)
 enum KernelClass {
     KC_GEMM_FWD = 0, KC_GEMM_DX, KC_GEMM_DW, KC_GEMM_REDUCE, KC_AGG_FWD, KC_AGG_BWD, KC_ETAB, KC_EMBED, KC_TABLE_GRAD,
-    KC_POOL, KC_PAIR_GATHER, KC_PAIR_SCATTER, KC_GRU_FWD, KC_GRU_BWD, KC_CE, KC_HEAD, KC_ADAM, KC_COUNT
+    KC_POOL, KC_PAIR_GATHER, KC_PAIR_SCATTER, KC_GRU_FWD, KC_GRU_BWD, KC_CE, KC_HEAD, KC_ADAM, KC_GINE_LAYER, KC_SCORER, KC_COUNT
 };
 struct ProfScope {
     ProfScope(hipStream_t s, int kc, double work);
@@ -91,6 +91,41 @@ int gine_agg_bwd(hipStream_t s, const AggBwdGroup* g, int ngroups, int ldda, int
 constexpr int ETAB_SEGMENTS = 32;
 struct EtabFinalGroup { const float* partial; float* seg_partial; float* d_edge_w; float* d_edge_b; };
 int gine_etab_final(hipStream_t s, const EtabFinalGroup* g, int ngroups, int np, int H);
+
+// One GINE application in one launch: aggregation (as the producer of the first product's operand) -> Linear +
+// ReLU -> Linear; agg / hid ([n, H] each) are written only when `save` (backward needs them), never re-read.
+struct FusedLayerGroup {
+    const float* x;                               // layer input [n, ldx]
+    const int32_t *rowptr, *col, *etype;          // CSR by target
+    const float *edge_w, *edge_b;
+    const float *w1p, *b1, *w2p, *b2;             // conv.nn.seq.{0,2}: weights PACKED by fused_pack, biases
+    float *agg, *hid;                             // saved for backward, or null
+    float* y;                                     // [n, ldy]
+    float ope;                                    // 1 + eps
+    int E;                                        // edge count (work accounting only)
+};
+bool gine_layer_fused_supported(int H, int ldx, int ldy);
+// Weights as the fused kernels read them: a [N][K] matrix (row pitch ld; `transposed`: stored as [K][N]) re-laid as
+// [ceil(K/16)][4][Npad][4] so that a wave's operand fragment is four 256-byte runs; fused_pack_floats = its size.
+struct FusedPack { const float* src; float* dst; int N, K, ld; bool transposed; };
+size_t fused_pack_floats(int N, int K);
+int fused_pack(hipStream_t s, const FusedPack* d, int count);   // up to 8 matrices in one launch
+int gine_layer_fwd(hipStream_t s, const FusedLayerGroup* g, int ngroups, int ldx, int ldy, int n, int H, bool save);
+
+// The link scorer's forward pass in one launch: pair gather -> MLP(P, P/2, P, ReLU, 3) -> Linear(P, 4) + cross-entropy
+// rows.  `packed`: scorer_pack_floats floats written by scorer_pack (once per step).  pin [S,P], s1/s2 [S,P/2],
+// s3 [S,P], logits [S,4], row_loss/lse [S] are the copies backward reads.
+struct ScorerFwd {
+    const float* emb; int lde; const float* z;
+    const int32_t *src, *dst, *graph, *gold;
+    const float* packed; const float *b0, *b1, *b2, *w3, *b3;
+    float *pin, *s1, *s2, *s3, *logits, *row_loss, *lse;
+    int S, H, Z;
+};
+bool scorer_fused_supported(int H, int Z, int lde);
+size_t scorer_pack_floats(int H, int Z);
+int scorer_pack(hipStream_t s, const float* w0, const float* w1, const float* w2, float* packed, int H, int Z);
+int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f);
 
 int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32_t* q, const float* ta,
                   const float* tp, const float* tq, int da, int dp, int dq, float* out, int n);

@@ -51,7 +51,7 @@ struct WS {
     float *pin, *s1, *s2, *s3, *slog, *rowloss_e, *lse_e, *q1, *q2, *pred, *mse_row, *losses;
     // backward
     float *dpred, *dq2, *dq1, *dz, *dz_piece, *dz_pair, *gscale, *dhseq, *dgi, *dgh, *dh0, *dsemb, *ds3, *ds2, *ds1, *dpin;
-    float *dmulv, *dcond, *dpooled, *GE, *GD, *G0, *DHE, *DHD, *DAE, *DAD, *dX0, *etab_part;
+    float *dmulv, *dcond, *dpooled, *GE, *GD, *G0, *DHE, *DHD, *DAE, *DAD, *dX0, *etab_part, *wpack, *spack;
     float *tg_part; size_t tg_part_floats;
     float *scratch, *scratch1, *scratch2; size_t scratch_floats;
     float* gru_exch; size_t gru_exch_bytes;
@@ -98,6 +98,8 @@ size_t carve(const Sz& s, float* base, WS* w, const char* want, int64_t* want_of
         {"enc_dagg", &WS::DAE, n * s.te * H}, {"dec_dagg", &WS::DAD, n * s.td * H},
         {"d_x0", &WS::dX0, n * s.Din}, {"etab_part", &WS::etab_part, 2 * (tmax * chunks + ETAB_SEGMENTS) * 4 * H},
         {"table_grad_part", &WS::tg_part, tg_part}, {"gru_exchange", &WS::gru_exch, gru_exch_bytes / 4},
+        {"packed_weights", &WS::wpack, 8 * fused_pack_floats(s.H, s.H)},
+        {"packed_scorer", &WS::spack, 2 * scorer_pack_floats(s.H, s.Z)},
         {"scratch", &WS::scratch, scratch}, {"scratch1", &WS::scratch1, scratch}, {"scratch2", &WS::scratch2, scratch},
     };
     size_t off = 0;
@@ -114,6 +116,7 @@ struct Stack {  // one GINE stack
     float *X, *A, *Hid, *Gr, *DH, *DA;
     const int32_t *rowptr, *col, *etype, *rowptr_t, *col_t, *etype_t;
     const float *node_w, *node_b, *edge_w, *edge_b, *w1, *b1, *w2, *b2;
+    float *w1p, *w2p;     // conv.nn weights re-laid for the fused layer kernel (workspace, written once per call)
     float *g_node_w, *g_node_b, *g_edge_w, *g_edge_b, *g_w1, *g_b1, *g_w2, *g_b2;
     float ope; int t; int E;
 };
@@ -124,6 +127,7 @@ Stack enc_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
     k.rowptr = b.rowptr; k.col = b.col; k.etype = b.etype; k.rowptr_t = b.rowptr_t; k.col_t = b.col_t; k.etype_t = b.etype_t;
     k.node_w = p.enc_node_w; k.node_b = p.enc_node_b; k.edge_w = p.enc_edge_w; k.edge_b = p.enc_edge_b;
     k.w1 = p.enc_w1; k.b1 = p.enc_b1; k.w2 = p.enc_w2; k.b2 = p.enc_b2;
+    k.w1p = w.wpack; k.w2p = w.wpack + fused_pack_floats(d.hidden, d.hidden);
     if (g) { k.g_node_w = g->enc_node_w; k.g_node_b = g->enc_node_b; k.g_edge_w = g->enc_edge_w; k.g_edge_b = g->enc_edge_b;
              k.g_w1 = g->enc_w1; k.g_b1 = g->enc_b1; k.g_w2 = g->enc_w2; k.g_b2 = g->enc_b2; }
     k.ope = 1.0f + d.eps_enc; k.t = d.t_enc; k.E = b.E;
@@ -136,6 +140,7 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
     k.rowptr_t = b.in_rowptr_t; k.col_t = b.in_col_t; k.etype_t = b.in_etype_t;
     k.node_w = p.dec_node_w; k.node_b = p.dec_node_b; k.edge_w = p.dec_edge_w; k.edge_b = p.dec_edge_b;
     k.w1 = p.dec_w1; k.b1 = p.dec_b1; k.w2 = p.dec_w2; k.b2 = p.dec_b2;
+    k.w1p = w.wpack + 2 * fused_pack_floats(d.hidden, d.hidden); k.w2p = w.wpack + 3 * fused_pack_floats(d.hidden, d.hidden);
     if (g) { k.g_node_w = g->dec_node_w; k.g_node_b = g->dec_node_b; k.g_edge_w = g->dec_edge_w; k.g_edge_b = g->dec_edge_b;
              k.g_w1 = g->dec_w1; k.g_b1 = g->dec_b1; k.g_w2 = g->dec_w2; k.g_b2 = g->dec_b2; }
     k.ope = 1.0f + d.eps_dec; k.t = d.t_dec; k.E = b.E_in;
@@ -143,7 +148,13 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
 }
 
 // Forward of 1 or 2 stacks with the same t: node_trans, then t x (aggregate, Linear+ReLU, Linear).
-int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng) {
+// `packed` (or null): an event after which the stacks' packed weights are in place (written by the caller on
+// another stream); without it they are packed here.
+bool fused_layers_on() {
+    static const bool on = [] { const char* e = getenv("PSVAE_FUSED_LAYER"); return !(e && e[0] == '0'); }();
+    return on;
+}
+int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng, bool save = true, hipEvent_t packed = nullptr) {
     const int n = s.n, H = s.H, t = k[0].t;
     const size_t nH = (size_t)n * H;   // the layer stack is slice-major: [t+1][n][H]
     const int64_t dX = ng == 2 ? k[1].X - k[0].X : 0, dA = ng == 2 ? k[1].A - k[0].A : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
@@ -154,6 +165,27 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
         if (ng == 2) { d.seg_b = k[1].node_w - k[0].node_w; d.seg_bias = k[1].node_b - k[0].node_b; d.seg_c = dX; }
         d.scratch = w.scratch; d.scratch_floats = w.scratch_floats;
         PSVAE_TRY(gemm_f32(st, d));
+    }
+    // one launch per GINE application where the fused kernel takes the size (PSVAE_FUSED_LAYER=0: three launches)
+    const bool fused = fused_layers_on() && gine_layer_fused_supported(H, H, H);
+    if (fused && packed) {
+        if (hipStreamWaitEvent(st, packed, 0) != hipSuccess) return (int)hipGetLastError();
+    } else if (fused) {    // the weights in the matrix cores' fragment order, once for all t applications
+        FusedPack pk[4];
+        for (int q = 0; q < ng; ++q) {
+            pk[2 * q] = FusedPack{k[q].w1, k[q].w1p, H, H, H, false};
+            pk[2 * q + 1] = FusedPack{k[q].w2, k[q].w2p, H, H, H, false};
+        }
+        PSVAE_TRY(fused_pack(st, pk, 2 * ng));
+    }
+    for (int l = 0; fused && l < t; ++l) {
+        FusedLayerGroup fg[2];
+        for (int q = 0; q < ng; ++q)
+            fg[q] = FusedLayerGroup{k[q].X + (size_t)l * nH, k[q].rowptr, k[q].col, k[q].etype, k[q].edge_w, k[q].edge_b,
+                                    k[q].w1p, k[q].b1, k[q].w2p, k[q].b2, save ? k[q].A + (size_t)l * nH : nullptr,
+                                    save ? k[q].Hid + (size_t)l * nH : nullptr, k[q].X + (size_t)(l + 1) * nH, k[q].ope, k[q].E};
+        PSVAE_TRY(gine_layer_fwd(st, fg, ng, H, H, n, H, save));
+        if (l == t - 1) return 0;
     }
     for (int l = 0; l < t; ++l) {
         AggGroup ag[2];
@@ -333,17 +365,17 @@ int rows_linear_fwd(hipStream_t st, const float* x, int ldx, const float* wt, co
 
 // Encoder half shared by the training step and psvae_encode: x0 .. mulv.
 int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, const psvae_batch& b, const Sz& s,
-                    const WS& w, bool with_decoder_stack, bool with_rsample) {
+                    const WS& w, bool with_decoder_stack, bool with_rsample, hipEvent_t packed = nullptr) {
     PSVAE_TRY(embed3_gather(st, b.atom_id, b.piece_id, b.pos_id, p.atom_emb, p.piece_emb, p.pos_emb, s.Da, s.Dp, s.Dq, w.X0, s.n));
     const float* cond = b.conds ? b.conds : w.cond;
     Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
     if (b.conds) {   // decoder-only: the conditions come from the caller, only the decoder-side stack runs
-        PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1));
+        PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1, with_rsample, packed));
     } else if (with_decoder_stack && s.te == s.td) {
-        PSVAE_TRY(stacks_forward(st, s, w, k, 2));
+        PSVAE_TRY(stacks_forward(st, s, w, k, 2, with_rsample, packed));
     } else {
-        PSVAE_TRY(stacks_forward(st, s, w, &k[0], 1));
-        if (with_decoder_stack) PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1));
+        PSVAE_TRY(stacks_forward(st, s, w, &k[0], 1, with_rsample, packed));
+        if (with_decoder_stack) PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1, with_rsample, packed));
     }
     if (!b.conds) {
         PSVAE_TRY(segment_pool_fwd(st, w.XE + (size_t)s.n * s.H, s.H, (int64_t)s.n * s.H, s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
@@ -397,14 +429,45 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     // lane 1 starts with the part of the piece branch that needs no latent: token embeddings and
     // the GRU input products for all steps (src/modules/vae_piece_decoder.py:82,87-89)
     if (L) PSVAE_TRY(hand_over(st, s1, L->ev[0]));
+    // lane 2 first lays the weights of the fused kernels out in the matrix cores' fragment order (GINE MLPs of both
+    // stacks, link scorer): off the dependent chain, which needs them only after the embeddings and node_trans
+    const bool dec_only = b.conds != nullptr;
+    const bool fused_gine = fused_layers_on() && gine_layer_fused_supported(s.H, s.H, s.H);
+    const bool fused_scorer = fused_layers_on() && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    hipEvent_t packed = nullptr;
+    if (L && (fused_gine || fused_scorer)) {
+        PSVAE_TRY(hand_over(st, s2, L->ev[5]));
+        if (fused_gine) {
+            const Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
+            FusedPack pk[4];
+            int cnt = 0;
+            for (int q = dec_only ? 1 : 0; q < 2; ++q) {
+                pk[cnt++] = FusedPack{k[q].w1, k[q].w1p, s.H, s.H, s.H, false};
+                pk[cnt++] = FusedPack{k[q].w2, k[q].w2p, s.H, s.H, s.H, false};
+            }
+            PSVAE_TRY(fused_pack(s2, pk, cnt));
+        }
+        if (fused_scorer) PSVAE_TRY(scorer_pack(s2, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
+        if (hipEventRecord(L->ev[6], s2) != hipSuccess) return (int)hipGetLastError();
+        packed = L->ev[6];
+    } else if (fused_scorer) {
+        PSVAE_TRY(scorer_pack(st, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
+    }
     PSVAE_TRY(rows_gather(s1, b.pieces, 0, s.T, s.L, p.piece_emb, s.Dp, w.semb, s.BT));
     PSVAE_TRY(linear_fwd(s1, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch1, scf));
     PSVAE_TRY(gru_exchange_clear(s1, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));   // long before z arrives
     // main: encoder and decoder-side GINE stacks, pooling, latent
-    PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true, true));
+    PSVAE_TRY(encoder_to_mulv(st, d, p, b, s, w, true, true, fused_gine ? packed : nullptr));
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[1])); PSVAE_TRY(hand_over(st, s2, L->ev[2])); }
     // (the scorer, the longest of the three branches, is queued first)
     // main: link scorer (src/modules/vae_piece_decoder.py:97-110)
+    if (fused_scorer) {     // gather, the three Linear layers, Linear(P -> 4) and the cross-entropy rows in one launch
+        if (packed && !fused_gine && hipStreamWaitEvent(st, packed, 0) != hipSuccess) return (int)hipGetLastError();
+        ScorerFwd f{w.XD + (size_t)s.td * s.n * s.H, s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, b.pair_gold, w.spack,
+                    p.sc_b0, p.sc_b1, p.sc_b2, p.sc_w3, p.sc_b3, w.pin, w.s1, w.s2, w.s3, w.slog, w.rowloss_e, w.lse_e,
+                    s.S, s.H, s.Z};
+        PSVAE_TRY(scorer_fwd_fused(st, f));     // (the packed weights were waited for before the GINE layers, or packed on this stream)
+    } else {
     PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.n * s.H, s.H, w.z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
     PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));
     PSVAE_TRY(linear_fwd(st, w.s1, s.P2, p.sc_w1, p.sc_b1, w.s2, s.P2, s.S, s.P2, s.P2, 1, w.scratch, scf));
@@ -415,13 +478,13 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
         PSVAE_TRY(linear_fwd(st, w.s3, s.P, p.sc_w3, p.sc_b3, w.slog, 4, s.S, 4, s.P, 0, w.scratch, scf));
         PSVAE_TRY(softmax_ce_fwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.rowloss_e, w.lse_e));
     }
+    }
     // lane 1: GRU + vocabulary logits + piece loss rows
     PSVAE_TRY(rows_linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, w.scratch1, scf));
     PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
     PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
     // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
-    const bool dec_only = b.conds != nullptr;
     if (!dec_only) {
         PSVAE_TRY(linear_fwd(s2, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch2, scf));
         PSVAE_TRY(linear_fwd(s2, w.q1, s.Hp, p.pred_w1, p.pred_b1, w.q2, s.Hp, s.B, s.Hp, s.Hp, 1, w.scratch2, scf));
@@ -644,7 +707,7 @@ extern "C" int psvae_score_links(const psvae_dims* dims, const psvae_params* par
     const size_t scf = w.scratch_floats;
     PSVAE_TRY(embed3_gather(st, b.atom_id, b.piece_id, b.pos_id, p.atom_emb, p.piece_emb, p.pos_emb, s.Da, s.Dp, s.Dq, w.X0, s.n));
     const Stack k = dec_stack(d, p, nullptr, b, w);
-    PSVAE_TRY(stacks_forward(st, s, w, &k, 1));
+    PSVAE_TRY(stacks_forward(st, s, w, &k, 1, false));
     if (s.S == 0) return 0;
     PSVAE_TRY(pair_gather(st, w.XD + (size_t)s.td * s.n * s.H, s.H, z, b.pair_src, b.pair_dst, b.pair_graph, w.pin, s.S, s.H, s.Z));
     PSVAE_TRY(linear_fwd(st, w.pin, s.P, p.sc_w0, p.sc_b0, w.s1, s.P2, s.S, s.P2, s.P, 1, w.scratch, scf));

@@ -91,6 +91,57 @@ def test_stress_full_size_is_sum_of_its_parts():
     check_close(g_parts, g_whole, 'gradient of the whole batch vs sum over halves', rtol=1e-4, atol_scale=2e-5, bad_frac=1e-3)
 
 
+@pytest.mark.parametrize('B', [256, 512])
+def test_vocab500_per_gpu_workloads_of_the_data_parallel_configuration(B):
+    """Vocabulary 500 with 256 and 512 graphs per GPU: what one GPU holds when the global batch of 1024 is split
+    over 4 and 2 of them.  A 48-graph slice of the batch is checked against the oracle (activations, losses,
+    all gradients); the whole batch through size-independent properties: its loss sums equal the sums over its
+    four quarters, its gradient equals the quarters' gradients (each divided by the whole batch's counts, as the
+    data-parallel step divides) added up, and two runs are bitwise identical."""
+    import random
+    from ps_vae_amd import synth
+    V = 500
+    d = O.default_dims(V)
+    model, tok, sd = build(d, V)
+    mols = synth.make_molecules(900 + B, 'zinc', V, B)
+    eps = torch.randn(B, d['latent'], generator=torch.Generator().manual_seed(21))
+    # oracle on a slice
+    from ps_vae_amd.data import BPEMolDataset, to_device
+    random.seed(5)
+    ref_slice = CO.collate([CO.to_matrix_form(m) for m in mols[:48]], V)
+    random.seed(5)
+    slice_ = to_device(BPEMolDataset.process_step3([BPEMolDataset.process_step2(m, tok) for m in mols[:48]], tok), 'cuda:0')
+    compare_forward_backward(model, d, sd, ref_slice, slice_, eps[:48], with_fp64=True)
+    # whole batch = its quarters
+    eps = eps.cuda()
+    q = B // 4
+    random.seed(6)          # one stream of negative-pair draws, consumed quarter after quarter = whole batch in order
+    parts = [to_device(BPEMolDataset.process_step3([BPEMolDataset.process_step2(m, tok) for m in mols[k * q:(k + 1) * q]], tok), 'cuda:0')
+             for k in range(4)]
+    random.seed(6)
+    whole = to_device(BPEMolDataset.process_step3([BPEMolDataset.process_step2(m, tok) for m in mols], tok), 'cuda:0')
+    assert whole['_native'].sizes['S'] == sum(p['_native'].sizes['S'] for p in parts)
+    assert whole['_native'].sizes['B'] == B and whole['_native'].sizes['n'] > 20 * B
+
+    def grads_of(batch, e, denoms=None):
+        if denoms is not None:
+            batch['_native'].denoms.copy_(denoms)
+        model.zero_grad()
+        model.global_step = 1000
+        model.training_step(batch, eps=e).backward()
+        return model.flat_buffers()[1].clone()
+
+    sums_whole = _loss_sums(model, whole, eps)
+    sums_parts = sum(_loss_sums(model, parts[k], eps[k * q:(k + 1) * q]) for k in range(4))
+    assert torch.allclose(sums_whole, sums_parts, rtol=2e-5), (sums_whole, sums_parts)
+    g_whole = grads_of(whole, eps)
+    assert torch.equal(g_whole, grads_of(whole, eps)), 'two runs of the same step differ'
+    den = whole['_native'].denoms.clone()
+    g_parts = sum(grads_of(parts[k], eps[k * q:(k + 1) * q], den) for k in range(4))
+    check_close(g_parts, g_whole, 'gradient of the whole batch vs sum over quarters', rtol=1e-4, atol_scale=2e-5, bad_frac=1e-3)
+    assert not model.recurrence_gave_up()
+
+
 def test_encode_4096_graphs_equals_its_parts_and_the_oracle():
     """Encoder-only path at the size of the bulk-encoding configuration (4096 ZINC-shape graphs, about
     95 k atoms): every graph's latent mean must equal what a 64-graph batch holding it gives, and that

@@ -229,3 +229,91 @@ def test_clip_adam_matches_torch():
                                      0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step, norm.data_ptr(), st))
         assert abs(float(norm) - float(want_norm)) <= 1e-5 * float(want_norm)
         check_close(p, pr.detach(), f'params after step {step}', rtol=1e-6, atol_scale=1e-6)
+
+
+@pytest.mark.parametrize('n,E,H,save', [(2964, 6400, 300, True), (95, 160, 300, False), (33, 0, 64, True), (1, 0, 16, True),
+                                        (700, 5000, 512, True), (5000, 9000, 328, False), (40, 400, 20, True)])
+def test_gine_layer_fused_forward(n, E, H, save):
+    """One GINE application in one launch (aggregation -> Linear + ReLU -> Linear) against plain fp32 torch; the
+    copies of agg and hid it leaves for backward must equal the intermediate results; graphs with nodes of many
+    bonds (more than the four fetched per round, more than the eight staged per node), with none, ragged last
+    row tile."""
+    from ps_vae_amd import _lib, ops
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    ei, et = _random_graph(n, E, seed=n + 1)
+    x, ew, eb = _rand(n, H, seed=1), _rand(H, 4, seed=2), _rand(H, seed=3, scale=0.1)
+    w1, b1 = _rand(H, H, seed=5, scale=H ** -0.5), _rand(H, seed=6, scale=0.1)
+    w2, b2 = _rand(H, H, seed=7, scale=H ** -0.5), _rand(H, seed=8, scale=0.1)
+    e = F.linear(F.one_hot(et, 4).float(), ew, eb)
+    agg_ref = torch.zeros_like(x).index_add_(0, ei[1], torch.relu(x.index_select(0, ei[0]) + e)) + 1.5 * x
+    hid_ref = torch.relu(F.linear(agg_ref, w1, b1))
+    y_ref = F.linear(hid_ref, w2, b2)
+    csr = ops.Csr(ei.to(dev()), et.to(dev()), n)
+    d = [t.to(dev()).contiguous() for t in (x, ew, eb, w1, b1, w2, b2)]
+    ldy = H + 8
+    y = torch.full((n, ldy), float('nan'), device=dev())
+    agg = torch.full((n, H), float('nan'), device=dev()) if save else None
+    hid = torch.full((n, H), float('nan'), device=dev()) if save else None
+    nbytes = L.psvae_gine_layer_scratch_bytes(H)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    _lib.check(L.psvae_gine_layer_forward(d[0].data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.etype.data_ptr(),
+                                          d[1].data_ptr(), d[2].data_ptr(), 1.5, d[3].data_ptr(), d[4].data_ptr(),
+                                          d[5].data_ptr(), d[6].data_ptr(), agg.data_ptr() if save else None,
+                                          hid.data_ptr() if save else None, y.data_ptr(), ldy, n, H, scratch.data_ptr(), nbytes, st))
+    check_close(y[:, :H], y_ref, 'fused layer output')
+    assert bool(torch.isnan(y[:, H:]).all()), 'columns past H of the output rows must stay untouched'
+    if save:
+        check_close(agg, agg_ref, 'saved aggregate')
+        check_close(hid, hid_ref, 'saved hidden')
+    # same aggregate as the stand-alone kernel, bit for bit (same sum order)
+    if save:
+        alone = ops.GineAggregateFn.apply(d[0], d[1], d[2], csr, 1.5)
+        assert torch.equal(alone, agg)
+    assert L.psvae_gine_layer_forward(d[0].data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.etype.data_ptr(),
+                                      d[1].data_ptr(), d[2].data_ptr(), 1.5, d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+                                      d[6].data_ptr(), None, hid.data_ptr() if save else y.data_ptr(), y.data_ptr(), ldy, n, H,
+                                      scratch.data_ptr(), nbytes, st) == -1      # agg and hid: both or neither
+    assert L.psvae_gine_layer_forward(d[0].data_ptr(), H, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.etype.data_ptr(),
+                                      d[1].data_ptr(), d[2].data_ptr(), 1.5, d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+                                      d[6].data_ptr(), None, None, y.data_ptr(), ldy, n, H, scratch.data_ptr(), nbytes - 16,
+                                      st) == -4      # scratch too small
+
+
+@pytest.mark.parametrize('S,n,B', [(3000, 2964, 128), (17, 40, 3), (1, 5, 1), (4113, 600, 33)])
+def test_scorer_fused_forward(S, n, B):
+    """The link scorer's forward pass in one launch (gather, three Linear layers, Linear(P, 4), cross-entropy
+    rows) against plain fp32 torch, including every activation it leaves behind for backward."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    H, Z = 300, 56
+    P, P2 = 2 * H + Z, (2 * H + Z) // 2
+    g = torch.Generator().manual_seed(S)
+    emb, z = _rand(n, H, seed=1), _rand(B, Z, seed=2)
+    src, dst = torch.randint(0, n, (S,), generator=g), torch.randint(0, n, (S,), generator=g)
+    gr, gold = torch.randint(0, B, (S,), generator=g), torch.randint(0, 4, (S,), generator=g)
+    w0, b0 = _rand(P2, P, seed=3, scale=P ** -0.5), _rand(P2, seed=4, scale=0.1)
+    w1, b1 = _rand(P2, P2, seed=5, scale=P2 ** -0.5), _rand(P2, seed=6, scale=0.1)
+    w2, b2 = _rand(P, P2, seed=7, scale=P2 ** -0.5), _rand(P, seed=8, scale=0.1)
+    w3, b3 = _rand(4, P, seed=9, scale=P ** -0.5), _rand(4, seed=10, scale=0.1)
+    pin_ref = torch.cat([emb[src], emb[dst], z[gr]], -1)
+    h1_ref = torch.relu(F.linear(pin_ref, w0, b0))
+    h2_ref = torch.relu(F.linear(h1_ref, w1, b1))
+    h3_ref = F.linear(h2_ref, w2, b2)
+    lg_ref = F.linear(h3_ref, w3, b3)
+    lse_ref = torch.logsumexp(lg_ref, -1)
+    loss_ref = F.cross_entropy(lg_ref, gold, reduction='none')
+    d = [t.to(dev()).contiguous() for t in (emb, z, w0, b0, w1, b1, w2, b2, w3, b3)]
+    idx = [t.to(dev()).to(torch.int32).contiguous() for t in (src, dst, gr, gold)]
+    out = [torch.full(shape, float('nan'), device=dev()) for shape in ((S, P), (S, P2), (S, P2), (S, P), (S, 4), (S,), (S,))]
+    nbytes = L.psvae_scorer_scratch_bytes(H, Z)
+    assert nbytes > 0 and L.psvae_scorer_scratch_bytes(512, 56) == 0
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    _lib.check(L.psvae_scorer_forward(d[0].data_ptr(), H, d[1].data_ptr(), *[t.data_ptr() for t in idx],
+                                      *[t.data_ptr() for t in d[2:]], *[t.data_ptr() for t in out], S, H, Z,
+                                      scratch.data_ptr(), nbytes, st))
+    for got, want, name in zip(out, (pin_ref, h1_ref, h2_ref, h3_ref, lg_ref, loss_ref, lse_ref),
+                               ('pair_in', 'h1', 'h2', 'h3', 'logits', 'row_loss', 'lse')):
+        check_close(got, want, name, atol_scale=2e-5)
+    assert torch.equal(out[0].cpu(), pin_ref)           # the gather copies bits

@@ -17,7 +17,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     # a step starts at the normal-distribution kernel that draws eps
-    starts = [i for i, r in enumerate(rows) if 'normal_and_transform' in r['Kernel_Name'] or 'distribution_elementwise' in r['Kernel_Name']]
+    starts = [i for i, r in enumerate(rows) if 'normal_rows_kernel' in r['Kernel_Name'] or 'normal_and_transform' in r['Kernel_Name'] or 'distribution_elementwise' in r['Kernel_Name']]
     k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
     lo, hi = starts[k], starts[k + 1]
     t0 = int(rows[lo]['Start_Timestamp'])
