@@ -34,7 +34,8 @@ from ps_vae_amd.parallel import GradReducer, OverlappedReducer, shard_range  # n
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-FLOP_CLASSES = ('gemm_forward', 'gemm_input_grad', 'gemm_weight_grad', 'gru_forward', 'gru_backward')
+FLOP_CLASSES = ('gemm_forward', 'gemm_input_grad', 'gemm_weight_grad', 'gru_forward', 'gru_backward', 'gine_layer_fused',
+                'scorer_fused')
 
 
 def make_batches(tok, vocab, shape, batch_size, count, seed, host_times=None):

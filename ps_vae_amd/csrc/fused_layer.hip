@@ -57,14 +57,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
 // acc[rt][ct] += img[rows of tile rt][0 .. 16 KB) . W[columns of tile ct][same k], W packed as above.  RT 16-row
 // tiles per workgroup (image rows rt * 16 + (l & 15)), CT 16-column tiles per wave.
 template <int CT, int RT>
-__device__ __forceinline__ void fl_product(const float* img, int P, const float* __restrict__ Wp, int KB, int rot, int wave,
-                                           int lane, floatx4 (&acc)[RT][CT]) {
-    // Every workgroup of a launch streams the SAME packed matrix; started together and walking it in the same order
-    // they would all ask the same few L2 channels for the same lines at the same moment (measured: 4-5 TB/s over
-    // the whole GPU, the matrix cores a quarter to half busy).  So each workgroup starts its walk `rot` blocks
-    // into the reduction and wraps around: at any moment the workgroups read different parts of the matrix.
+__device__ __forceinline__ void fl_product(const float* img, int P, const float* __restrict__ Wp, int KB, int wave, int lane,
+                                           floatx4 (&acc)[RT][CT]) {
+    // (Every row's reduction runs in the same order wherever the row sits in the batch, so a graph's results do not
+    // depend on its neighbours.  Starting each workgroup at a different block of the reduction, to keep the
+    // workgroups from asking for the same lines of the matrix at the same moment, was measured and gains nothing.)
     const int nl = lane & 15, kq = lane >> 4;
-    const int kb0 = rot % KB;
     constexpr int Npad = 64 * CT;
     const float* wlane = Wp + ((size_t)kq * Npad + wave * CT * 16 + nl) * 4;      // + kb * 16 * Npad + ct * 64
     const float* arow = img + nl * P + 4 * kq;                                      // + rt * 16 * P + kb * 16
@@ -72,16 +70,12 @@ __device__ __forceinline__ void fl_product(const float* img, int P, const float*
     // blocks past the last one are clamped to it (fetched, never used)
 #define FL_LOADB(B_, KB_)                                                                          \
     {                                                                                              \
-        int kbr_ = min((KB_), KB - 1) + kb0;                                                       \
-        kbr_ -= kbr_ >= KB ? KB : 0;                                                               \
-        const float* p_ = wlane + (size_t)kbr_ * (16 * Npad);                                      \
+        const float* p_ = wlane + (size_t)min((KB_), KB - 1) * (16 * Npad);                        \
         _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) B_[ct] = fl_ld4(p_ + ct * 64);           \
     }
 #define FL_READA(A_, KB_)                                                                                   \
     {                                                                                                       \
-        int kbr_ = min((KB_), KB - 1) + kb0;                                                                \
-        kbr_ -= kbr_ >= KB ? KB : 0;                                                                        \
-        const int o_ = kbr_ * 16;                                                                           \
+        const int o_ = min((KB_), KB - 1) * 16;                                                             \
         _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                   \
             A_[rt] = *reinterpret_cast<const float4*>(arow + rt * 16 * P + o_);                             \
     }
@@ -282,15 +276,103 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_fwd_kernel(const FLArgs
     // ---- phase 2: hid = relu(agg W1^T + b1), back into the image
     floatx4 acc[FL_RT][CT];
     fl_zero<CT, FL_RT>(acc);
-    fl_product<CT, FL_RT>(img, P, g.w1p, KB, tile * 5, wave, lane, acc);
+    fl_product<CT, FL_RT>(img, P, g.w1p, KB, wave, lane, acc);
     __syncthreads();            // every wave is done reading the aggregated image
     fl_store<CT, FL_RT, true, true>(acc, bias1, H, img, P, 0, SAVE ? g.hid : nullptr, H, row0, n, wave, lane);
     __syncthreads();
 
     // ---- phase 3: y = hid W2^T + b2
     fl_zero<CT, FL_RT>(acc);
-    fl_product<CT, FL_RT>(img, P, g.w2p, KB, tile * 5 + 9, wave, lane, acc);
+    fl_product<CT, FL_RT>(img, P, g.w2p, KB, wave, lane, acc);
     fl_store<CT, FL_RT, false, false>(acc, bias2, H, nullptr, 0, 0, g.y, a.ldy, row0, n, wave, lane);
+}
+
+// Backward through a ReLU: v = acc where the saved forward activation `act` (global, [nrows, ldact]) is positive,
+// else 0; written to the LDS image (with zero padding up to the wave tiles' end) and to global rows.  The gate
+// values are requested first, then `pre_write_sync` lets the caller's barrier ("everyone is done reading the image
+// that is about to be overwritten") sit between the requests and their use.
+template <int CT, int RT, bool SYNC>
+__device__ __forceinline__ void fl_store_gated(const floatx4 (&acc)[RT][CT], const float* __restrict__ act, size_t ldact, int N,
+                                               float* img, int P, float* gout, size_t ldg, int row0, int nrows, int wave, int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+    float gate[RT][CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = min((wave * CT + ct) * 16 + nl, N - 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate[rt][ct][i] = act[(size_t)min(row0 + rt * 16 + 4 * kq + i, nrows - 1) * ldact + c];
+    }
+    if (SYNC) __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = (wave * CT + ct) * 16 + nl;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rt * 16 + 4 * kq + i;
+                const float v = (c < N && gate[rt][ct][i] > 0.f) ? acc[rt][ct][i] : 0.f;
+                if (c < P) img[r * P + c] = v;
+                if (c < N && row0 + r < nrows) gout[(size_t)(row0 + r) * ldg + c] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the two Linear layers of a GINE application as ONE launch:
+//     dHid = (G W2) * [hid > 0]        G = dL/dy of the layer (rows of the tile loaded into the LDS image)
+//     dAgg = dHid W1
+// W2 and W1 arrive packed in their transposed role (reduction over the weight matrix's ROW index).  dHid (needed by
+// the weight gradients of the first Linear) and dAgg (input of the aggregation's backward) go to memory; dHid never
+// comes back from there.
+struct FLBGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; };
+struct FLBArgs { FLBGroup g[2]; int n, H, P; };
+
+template <int CT>
+__global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_kernel(const FLBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    const FLBGroup& g = a.g[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, P = a.P, H4 = H >> 2, n = a.n, KB = (H + 15) >> 4;
+    float* img = fl_lds;
+    const int per_xcd = gridDim.x / 8, bx = blockIdx.x;
+    const int tile = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
+    const int row0 = tile * FL_ROWS;
+    {   // the tile's rows of G, all loads of a thread first
+        const int items = FL_ROWS * H4;
+        for (int it = tid; it < items; it += 4 * FL_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / H4, c = (t - r * H4) * 4;
+                v[u] = fl_ld4(g.g + (size_t)min(row0 + r, n - 1) * H + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = it + u * FL_THREADS;
+                if (t >= items) continue;
+                const int r = t / H4, c = (t - r * H4) * 4;
+                *reinterpret_cast<float4*>(img + r * P + c) = row0 + r < n ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const int padw = P - H;
+        for (int k = tid; k < FL_ROWS * padw; k += FL_THREADS) img[(k / padw) * P + H + (k % padw)] = 0.f;
+    }
+    __syncthreads();
+    floatx4 acc[FL_RT][CT];
+    fl_zero<CT, FL_RT>(acc);
+    fl_product<CT, FL_RT>(img, P, g.w2tp, KB, wave, lane, acc);
+    fl_store_gated<CT, FL_RT, true>(acc, g.hid, H, H, img, P, g.dh, H, row0, n, wave, lane);   // (barrier inside: G is no longer read)
+    __syncthreads();
+    fl_zero<CT, FL_RT>(acc);
+    fl_product<CT, FL_RT>(img, P, g.w1tp, KB, wave, lane, acc);
+    float nobias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) nobias[ct] = 0.f;
+    fl_store<CT, FL_RT, false, false>(acc, nobias, H, nullptr, 0, 0, g.da, H, row0, n, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -357,21 +439,21 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs
     floatx4 acc[1][CT];
     // s1
     fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgA, PA, a.w0p, (P + 15) >> 4, blockIdx.x * 7, wave, lane, acc);
+    fl_product<CT, 1>(imgA, PA, a.w0p, (P + 15) >> 4, wave, lane, acc);
     fl_store<CT, 1, true, true>(acc, bias0, P2, imgB, PB, 0, a.s1, P2, row0, S, wave, lane);
     __syncthreads();
     // s2 (in place)
     fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w1p, (P2 + 15) >> 4, blockIdx.x * 5, wave, lane, acc);
+    fl_product<CT, 1>(imgB, PB, a.w1p, (P2 + 15) >> 4, wave, lane, acc);
     __syncthreads();
     fl_store<CT, 1, true, true>(acc, bias1, P2, imgB, PB, 0, a.s2, P2, row0, S, wave, lane);
     __syncthreads();
     // s3, two halves, into the first image (the pair input is no longer needed)
     fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w2p_lo, (P2 + 15) >> 4, blockIdx.x * 5 + 3, wave, lane, acc);
+    fl_product<CT, 1>(imgB, PB, a.w2p_lo, (P2 + 15) >> 4, wave, lane, acc);
     fl_store<CT, 1, false, false>(acc, bias2lo, P2, imgA, PA, 0, a.s3, P, row0, S, wave, lane);
     fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w2p_hi, (P2 + 15) >> 4, blockIdx.x * 5 + 11, wave, lane, acc);
+    fl_product<CT, 1>(imgB, PB, a.w2p_hi, (P2 + 15) >> 4, wave, lane, acc);
     fl_store<CT, 1, false, false>(acc, bias2hi, P2, imgA, PA, P2, a.s3, P, row0, S, wave, lane);
     __syncthreads();
     // head: wave w takes rows 4w .. 4w+3; lanes split the P columns in float4 chunks
@@ -418,6 +500,67 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the link scorer's MLP as ONE launch (the head's backward has already turned the logits' gradient
+// into ds3 = dL/ds3):   ds2 = (ds3 W2) * [s2 > 0];   ds1 = (ds2 W1) * [s1 > 0];   dpin = ds1 W0.
+// 16 pairs per workgroup; ds2 / ds1 (operands of the weight gradients) and dpin (scattered to the atoms afterwards)
+// go to memory.  The weights arrive packed in their transposed role, W0 as two halves of P/2 output columns.
+struct ScorerBwdArgs {
+    const float *ds3, *s2, *s1;
+    const float *w2tp, *w1tp, *w0tp_lo, *w0tp_hi;
+    float *ds2, *ds1, *dpin;
+    int S, P, P2, PA, PB;
+};
+
+template <int CT>
+__global__ __launch_bounds__(FL_THREADS) void scorer_bwd_kernel(const ScorerBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 16, S = a.S, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
+    float* imgA = fl_lds;              // [16][PA]: ds3
+    float* imgB = fl_lds + 16 * PA;    // [16][PB]: ds2, then ds1
+    {
+        const int P4 = P >> 2, items = 16 * P4;
+        for (int it = tid; it < items; it += 4 * FL_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / P4, c = (t - r * P4) * 4;
+                v[u] = fl_ld4(a.ds3 + (size_t)min(row0 + r, S - 1) * P + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = it + u * FL_THREADS;
+                if (t >= items) continue;
+                const int r = t / P4, c = (t - r * P4) * 4;
+                *reinterpret_cast<float4*>(imgA + r * PA + c) = row0 + r < S ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int k = tid; k < 16 * (PA - P); k += FL_THREADS) imgA[(k / (PA - P)) * PA + P + k % (PA - P)] = 0.f;
+        for (int k = tid; k < 16 * (PB - P2); k += FL_THREADS) imgB[(k / (PB - P2)) * PB + P2 + k % (PB - P2)] = 0.f;
+    }
+    __syncthreads();
+    floatx4 acc[1][CT];
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgA, PA, a.w2tp, (P + 15) >> 4, wave, lane, acc);
+    fl_store_gated<CT, 1, false>(acc, a.s2, P2, P2, imgB, PB, a.ds2, P2, row0, S, wave, lane);
+    __syncthreads();
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgB, PB, a.w1tp, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store_gated<CT, 1, true>(acc, a.s1, P2, P2, imgB, PB, a.ds1, P2, row0, S, wave, lane);
+    __syncthreads();
+    float nobias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) nobias[ct] = 0.f;
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgB, PB, a.w0tp_lo, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store<CT, 1, false, false>(acc, nobias, P2, nullptr, 0, 0, a.dpin, P, row0, S, wave, lane);
+    fl_zero<CT, 1>(acc);
+    fl_product<CT, 1>(imgB, PB, a.w0tp_hi, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store<CT, 1, false, false>(acc, nobias, P2, nullptr, 0, P2, a.dpin, P, row0, S, wave, lane);
 }
 
 int fl_pitch(int K) {       // smallest pitch >= K rounded up to 16 with pitch = 8 mod 64
@@ -544,6 +687,74 @@ int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
     }
     ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P + 4.0 * P));
     hipLaunchKernelGGL(scorer_fwd_kernel<6>, dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, int H) {
+    if (n <= 0) return 0;
+    if (ng < 1 || ng > 2) return PSVAE_E_SHAPE;
+    if (!gine_layer_fused_supported(H, H, H)) return PSVAE_E_SHAPE;
+    FLBArgs a{};
+    for (int q = 0; q < ng; ++q) {
+        const FusedLayerBwdGroup& f = grp[q];
+        if (!f.g || !f.hid || !f.w2tp || !f.w1tp || !f.dh || !f.da) return PSVAE_E_NULL;
+        if (!aligned16(f.g) || !aligned16(f.w2tp) || !aligned16(f.w1tp)) return PSVAE_E_ALIGN;
+        a.g[q] = FLBGroup{f.g, f.hid, f.w2tp, f.w1tp, f.dh, f.da};
+    }
+    a.n = n; a.H = H; a.P = fl_pitch(H);
+    const size_t lds = (size_t)FL_ROWS * a.P * sizeof(float);
+    const int CT = fused_ct(H);
+    const dim3 grid((n + FL_ROWS - 1) / FL_ROWS, ng);
+    ProfScope prof(s, KC_GINE_LAYER, 4.0 * n * H * H * ng);
+#define FLB_LAUNCH(CT_)                                                                                               \
+    do {                                                                                                              \
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_bwd_kernel<CT_>,                           \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return (int)hipGetLastError();                                                                            \
+        hipLaunchKernelGGL((gine_layer_bwd_kernel<CT_>), grid, dim3(FL_THREADS), lds, s, a);                          \
+    } while (0)
+    if (CT == 5) FLB_LAUNCH(5);
+    else if (CT == 6) FLB_LAUNCH(6);
+    else FLB_LAUNCH(8);
+#undef FLB_LAUNCH
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// transposed-role packs for the scorer's backward: w2 [P, P2], w1 [P2, P2], w0 [P2, P] (two halves of P2 columns)
+int scorer_pack_bwd(hipStream_t s, const float* w0, const float* w1, const float* w2, float* packed, int H, int Z) {
+    const int P = 2 * H + Z, P2 = P / 2;
+    float* w2tp = packed;
+    float* w1tp = w2tp + fused_pack_floats(P2, P);
+    float* w0lo = w1tp + fused_pack_floats(P2, P2);
+    float* w0hi = w0lo + fused_pack_floats(P2, P2);
+    const FusedPack pk[4] = {{w2, w2tp, P2, P, P2, true}, {w1, w1tp, P2, P2, P2, true}, {w0, w0lo, P2, P2, P, true},
+                             {w0 + P2, w0hi, P2, P2, P, true}};
+    return fused_pack(s, pk, 4);
+}
+
+int scorer_bwd_fused(hipStream_t s, const ScorerBwd& f) {
+    if (f.S <= 0) return 0;
+    if (!scorer_fused_supported(f.H, f.Z, f.H)) return PSVAE_E_SHAPE;
+    const int P = 2 * f.H + f.Z, P2 = P / 2;
+    if (!f.ds3 || !f.s2 || !f.s1 || !f.packed || !f.ds2 || !f.ds1 || !f.dpin) return PSVAE_E_NULL;
+    if (!aligned16(f.ds3) || !aligned16(f.packed)) return PSVAE_E_ALIGN;
+    ScorerBwdArgs a{};
+    a.ds3 = f.ds3; a.s2 = f.s2; a.s1 = f.s1;
+    a.w2tp = f.packed; a.w1tp = a.w2tp + fused_pack_floats(P2, P); a.w0tp_lo = a.w1tp + fused_pack_floats(P2, P2);
+    a.w0tp_hi = a.w0tp_lo + fused_pack_floats(P2, P2);
+    a.ds2 = f.ds2; a.ds1 = f.ds1; a.dpin = f.dpin;
+    a.S = f.S; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
+    const size_t lds = (size_t)16 * (a.PA + a.PB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)scorer_bwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return (int)hipGetLastError();
+        attr_set = true;
+    }
+    ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P));
+    hipLaunchKernelGGL(scorer_bwd_kernel<6>, dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

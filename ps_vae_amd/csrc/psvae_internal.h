@@ -105,6 +105,10 @@ struct FusedLayerGroup {
     int E;                                        // edge count (work accounting only)
 };
 bool gine_layer_fused_supported(int H, int ldx, int ldy);
+// Backward of the two Linear layers of a GINE application in one launch: dh = (g w2) * [hid > 0], da = dh w1, with
+// w2tp / w1tp packed by fused_pack with `transposed` set (all matrices [n, H] / [H, H]).
+struct FusedLayerBwdGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; };
+int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* g, int ngroups, int n, int H);
 // Weights as the fused kernels read them: a [N][K] matrix (row pitch ld; `transposed`: stored as [K][N]) re-laid as
 // [ceil(K/16)][4][Npad][4] so that a wave's operand fragment is four 256-byte runs; fused_pack_floats = its size.
 struct FusedPack { const float* src; float* dst; int N, K, ld; bool transposed; };
@@ -126,6 +130,11 @@ bool scorer_fused_supported(int H, int Z, int lde);
 size_t scorer_pack_floats(int H, int Z);
 int scorer_pack(hipStream_t s, const float* w0, const float* w1, const float* w2, float* packed, int H, int Z);
 int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f);
+// Backward of the scorer's three Linear layers in one launch, given ds3 = dL/ds3 [S,P] (written by the head's backward):
+// ds2, ds1 [S,P/2] and dpin [S,P].  `packed`: scorer_pack_floats floats written by scorer_pack_bwd.
+struct ScorerBwd { const float *ds3, *s2, *s1, *packed; float *ds2, *ds1, *dpin; int S, H, Z; };
+int scorer_pack_bwd(hipStream_t s, const float* w0, const float* w1, const float* w2, float* packed, int H, int Z);
+int scorer_bwd_fused(hipStream_t s, const ScorerBwd& f);
 
 int embed3_gather(hipStream_t s, const int32_t* a, const int32_t* p, const int32_t* q, const float* ta,
                   const float* tp, const float* tq, int da, int dp, int dq, float* out, int n);

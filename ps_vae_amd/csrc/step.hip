@@ -117,6 +117,7 @@ struct Stack {  // one GINE stack
     const int32_t *rowptr, *col, *etype, *rowptr_t, *col_t, *etype_t;
     const float *node_w, *node_b, *edge_w, *edge_b, *w1, *b1, *w2, *b2;
     float *w1p, *w2p;     // conv.nn weights re-laid for the fused layer kernel (workspace, written once per call)
+    float *w1tp, *w2tp;   // the same in their transposed role (input gradients), written once per backward call
     float *g_node_w, *g_node_b, *g_edge_w, *g_edge_b, *g_w1, *g_b1, *g_w2, *g_b2;
     float ope; int t; int E;
 };
@@ -128,6 +129,7 @@ Stack enc_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
     k.node_w = p.enc_node_w; k.node_b = p.enc_node_b; k.edge_w = p.enc_edge_w; k.edge_b = p.enc_edge_b;
     k.w1 = p.enc_w1; k.b1 = p.enc_b1; k.w2 = p.enc_w2; k.b2 = p.enc_b2;
     k.w1p = w.wpack; k.w2p = w.wpack + fused_pack_floats(d.hidden, d.hidden);
+    k.w1tp = w.wpack + 4 * fused_pack_floats(d.hidden, d.hidden); k.w2tp = w.wpack + 5 * fused_pack_floats(d.hidden, d.hidden);
     if (g) { k.g_node_w = g->enc_node_w; k.g_node_b = g->enc_node_b; k.g_edge_w = g->enc_edge_w; k.g_edge_b = g->enc_edge_b;
              k.g_w1 = g->enc_w1; k.g_b1 = g->enc_b1; k.g_w2 = g->enc_w2; k.g_b2 = g->enc_b2; }
     k.ope = 1.0f + d.eps_enc; k.t = d.t_enc; k.E = b.E;
@@ -141,6 +143,7 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
     k.node_w = p.dec_node_w; k.node_b = p.dec_node_b; k.edge_w = p.dec_edge_w; k.edge_b = p.dec_edge_b;
     k.w1 = p.dec_w1; k.b1 = p.dec_b1; k.w2 = p.dec_w2; k.b2 = p.dec_b2;
     k.w1p = w.wpack + 2 * fused_pack_floats(d.hidden, d.hidden); k.w2p = w.wpack + 3 * fused_pack_floats(d.hidden, d.hidden);
+    k.w1tp = w.wpack + 6 * fused_pack_floats(d.hidden, d.hidden); k.w2tp = w.wpack + 7 * fused_pack_floats(d.hidden, d.hidden);
     if (g) { k.g_node_w = g->dec_node_w; k.g_node_b = g->dec_node_b; k.g_edge_w = g->dec_edge_w; k.g_edge_b = g->dec_edge_b;
              k.g_w1 = g->dec_w1; k.g_b1 = g->dec_b1; k.g_w2 = g->dec_w2; k.g_b2 = g->dec_b2; }
     k.ope = 1.0f + d.eps_dec; k.t = d.t_dec; k.E = b.E_in;
@@ -153,6 +156,20 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
 bool fused_layers_on() {
     static const bool on = [] { const char* e = getenv("PSVAE_FUSED_LAYER"); return !(e && e[0] == '0'); }();
     return on;
+}
+// The link scorer as one launch each way: built and parity-tested, but measured slower than the GEMM chain inside
+// the step at every batch size tried (16-row tiles stream the weights at the L1 fill limit and slow the GRU lane
+// that runs beside them), so it is opt-in: PSVAE_FUSED_SCORER=1.
+bool fused_scorer_on() {
+    static const bool on = [] { const char* e = getenv("PSVAE_FUSED_SCORER"); return e && e[0] == '1'; }();
+    return on && fused_layers_on();
+}
+// The fused backward of the GINE MLPs pays once a launch holds more row tiles than the GPU has compute units
+// (measured: -1.2 % at 128 graphs per step, +0.6 % at 256, +2.2 % at 512); PSVAE_FUSED_BWD=0 / 1 forces it off / on.
+bool fused_bwd_on(int n, int ng) {
+    static const int forced = [] { const char* e = getenv("PSVAE_FUSED_BWD"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (!fused_layers_on()) return false;
+    return forced >= 0 ? forced == 1 : (long long)((n + 31) / 32) * ng >= 320;
 }
 int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng, bool save = true, hipEvent_t packed = nullptr) {
     const int n = s.n, H = s.H, t = k[0].t;
@@ -225,7 +242,15 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
     const size_t nH = (size_t)n * H, nblk = (size_t)gine_agg_bwd_blocks(n, H);
     const int64_t dG = ng == 2 ? k[1].Gr - k[0].Gr : 0, dDH = ng == 2 ? k[1].DH - k[0].DH : 0;
     const int64_t dDA = ng == 2 ? k[1].DA - k[0].DA : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
+    const bool fused = fused_bwd_on(n, ng) && gine_layer_fused_supported(H, H, H);
     for (int l = t - 1; l >= 0; --l) {
+        if (fused) {    // dHid_l = (G_{l+1} W2) * (Hid_l > 0) and dAgg_l = dHid_l W1 in one launch
+            FusedLayerBwdGroup fg[2];
+            for (int q = 0; q < ng; ++q)
+                fg[q] = FusedLayerBwdGroup{k[q].Gr + (size_t)(l + 1) * nH, k[q].Hid + (size_t)l * nH, k[q].w2tp, k[q].w1tp,
+                                           k[q].DH + (size_t)l * nH, k[q].DA + (size_t)l * nH};
+            PSVAE_TRY(gine_layer_bwd(st, fg, ng, n, H));
+        } else {
         GemmDesc d2;  // dHid_l = (G_{l+1} W2) * (Hid_l > 0)
         d2.A = k[0].Gr + (size_t)(l + 1) * nH; d2.lda = H; d2.B = k[0].w2; d2.ldb = H; d2.b_t = true;
         d2.C = k[0].DH + (size_t)l * nH; d2.ldc = H; d2.M = n; d2.N = H; d2.R = H;
@@ -239,6 +264,7 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
         if (ng == 2) { d1.seg_a = dDH; d1.seg_b = k[1].w1 - k[0].w1; d1.seg_c = dDA; }
         d1.scratch = w.scratch; d1.scratch_floats = w.scratch_floats;
         PSVAE_TRY(gemm_f32(st, d1));
+        }
         AggBwdGroup ag[2];
         for (int q = 0; q < ng; ++q) {
             float* dx = l > 0 ? k[q].Gr + (size_t)l * nH : w.G0 + (size_t)(g0_slot0 + q) * H;
@@ -433,7 +459,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     // stacks, link scorer): off the dependent chain, which needs them only after the embeddings and node_trans
     const bool dec_only = b.conds != nullptr;
     const bool fused_gine = fused_layers_on() && gine_layer_fused_supported(s.H, s.H, s.H);
-    const bool fused_scorer = fused_layers_on() && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    const bool fused_scorer = fused_scorer_on() && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     hipEvent_t packed = nullptr;
     if (L && (fused_gine || fused_scorer)) {
         PSVAE_TRY(hand_over(st, s2, L->ev[5]));
@@ -519,6 +545,24 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     const GScale gs{loss_grads, loss_weights ? loss_weights[0] : 0.f, loss_weights ? loss_weights[1] : 0.f,
                     loss_weights ? loss_weights[2] : 0.f};
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[0])); PSVAE_TRY(hand_over(st, s2, L->ev[1])); }
+    // lane 2 first: the GINE MLP weights in their transposed role, laid out for the fused backward kernel (the
+    // dependent chain reaches the GINE stacks hundreds of microseconds later)
+    const bool dec_only_ = b.conds != nullptr;
+    const bool fused_gine = fused_bwd_on(s.n, (dec_only_ || s.te != s.td) ? 1 : 2) && gine_layer_fused_supported(s.H, s.H, s.H);
+    if (fused_gine) {
+        const Stack kk[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
+        FusedPack pk[4];
+        int cnt = 0;
+        for (int q = dec_only_ ? 1 : 0; q < 2; ++q) {
+            pk[cnt++] = FusedPack{kk[q].w1, kk[q].w1tp, s.H, s.H, s.H, true};
+            pk[cnt++] = FusedPack{kk[q].w2, kk[q].w2tp, s.H, s.H, s.H, true};
+        }
+        PSVAE_TRY(fused_pack(s2, pk, cnt));
+    }
+    const bool fused_scorer = fused_scorer_on() && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    float* spack_bwd = w.spack + scorer_pack_floats(s.H, s.Z);
+    if (fused_scorer) PSVAE_TRY(scorer_pack_bwd(s2, p.sc_w0, p.sc_w1, p.sc_w2, spack_bwd, s.H, s.Z));
+    if (L && (fused_gine || fused_scorer) && hipEventRecord(L->ev[15], s2) != hipSuccess) return (int)hipGetLastError();
     // the recurrence's exchange buffer is zeroed on lane 2, off the piece branch's dependent chain
     PSVAE_TRY(gru_exchange_clear(s2, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));
     if (L && hipEventRecord(L->ev[14], s2) != hipSuccess) return (int)hipGetLastError();
@@ -556,6 +600,18 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     const bool fused_pair_head = pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     if (fused_pair_head) PSVAE_TRY(pair_head_bwd(st, w.slog, w.lse_e, b.pair_gold, p.sc_w3, gs, b.denoms, w.ds3, s.P, s.S, s.P));
     else PSVAE_TRY(softmax_ce_bwd(st, w.slog, 4, b.pair_gold, 0, 0, s.S > 0 ? s.S : 1, s.S, 4, -1, w.lse_e, gs, 2, b.denoms, 1));
+    if (fused_scorer) {
+        // the three input-gradient products of the scorer's MLP in one launch; lane 2 takes the weight gradients
+        if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
+        PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc2, scf));
+        if (L && hipStreamWaitEvent(st, L->ev[15], 0) != hipSuccess) return (int)hipGetLastError();
+        ScorerBwd sb{w.ds3, w.s2, w.s1, spack_bwd, w.ds2, w.ds1, w.dpin, s.S, s.H, s.Z};
+        PSVAE_TRY(scorer_bwd_fused(st, sb));
+        if (L) PSVAE_TRY(hand_over(st, s2, L->ev[5]));
+        PSVAE_TRY(linear_bwd_w(s2, w.ds2, s.P2, 0, w.s1, s.P2, 0, 1, g.sc_w1, g.sc_b1, s.S, s.P2, s.P2, sc2, scf));
+        PSVAE_TRY(linear_bwd_w(s2, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc2, scf));
+    } else {
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
     PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
     if (!fused_pair_head) PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
@@ -568,6 +624,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[7]));
     PSVAE_TRY(linear_bwd_w(s2, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc2, scf));
     PSVAE_TRY(linear_bwd_x(st, w.ds1, s.P2, p.sc_w0, w.dpin, s.P, s.S, s.P2, s.P, nullptr, 0, 0));
+    }
     PSVAE_TRY(pair_scatter(st, w.dpin, s.P, b.pair_by_src_ptr, b.pair_by_src_idx, b.pair_by_dst_ptr, b.pair_by_dst_idx,
                            b.pair_graph_off, w.GD + (size_t)s.td * nH, s.H, w.dz_pair, 0, s.n, s.B, s.H, s.Z));
     // --- latent head and encoder.linear: needs the three parts of dL/dz
@@ -609,6 +666,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
         PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
     }
     const float* dpool[2] = {w.dpooled, nullptr};
+    if (L && fused_gine && hipStreamWaitEvent(st, L->ev[15], 0) != hipSuccess) return (int)hipGetLastError();
     if (dec_only) {
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1, 1));
     } else if (s.te == s.td) {

@@ -45,7 +45,10 @@ class NativeBatch:
         return self.blob.device
 
     def to(self, device, non_blocking=True):
-        if self.blob.device == torch.device(device):
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:      # 'cuda' names the current device
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self.blob.device == device:
             return self
         nb = NativeBatch(self.blob.to(device, non_blocking=non_blocking), self.offsets, self.sizes,
                          self.props.to(device, non_blocking=non_blocking),

@@ -135,6 +135,7 @@ class PSVAEModel(nn.Module):
         # epsilon of rsample: counter-based, keyed by (eps_seed, number of forward passes so far, global graph index)
         self.eps_seed = int(config.get('seed', 2021)) if hasattr(config, 'get') else 2021
         self.eps_draws = 0
+        self.shard_rank = 0          # set by parallel.make_reducer: this process's place among the data-parallel ranks
         self._dims = self._make_dims()
 
     # ------------------------------------------------------------------ layout
@@ -277,7 +278,7 @@ class PSVAEModel(nn.Module):
             raise RuntimeError('PSVAEModel runs on the GPU only: move it with .cuda() (no CPU implementation exists)')
         nb = self._native(batch)
         if eps is None:
-            eps = self.draw_eps(nb.sizes['B'], nb.graph_base or 0)
+            eps = self.draw_eps(nb.sizes['B'], self._first_graph(nb))
         eps = eps.to(self._flat.device, torch.float32).contiguous()
         alpha = float(self.config['alpha'])
         out, self._last_total = _StepFn.apply(self._trigger, self, nb, eps, (1.0 - alpha, alpha, float(self.cal_beta())))
@@ -285,6 +286,10 @@ class PSVAEModel(nn.Module):
         if return_accu:
             return pred_loss, (losses, self._accuracies(nb))
         return pred_loss, losses
+
+    def _first_graph(self, nb):
+        """Global index of a batch's first graph: what its loader recorded, else `shard_rank` equal shards in."""
+        return nb.graph_base if nb.graph_base is not None else self.shard_rank * nb.sizes['B']
 
     def draw_eps(self, rows, first_row=0):
         """The N(0,1) draw of `rsample` (`src/modules/vae_piece_decoder.py:61`) for graphs `first_row ..
@@ -415,7 +420,7 @@ class PSVAEModel(nn.Module):
             mean, lvar = self.encode(batch)
             if eps is None:
                 nb = self._native(batch)
-                eps = self.draw_eps(mean.shape[0], nb.graph_base or 0)
+                eps = self.draw_eps(mean.shape[0], self._first_graph(nb))
             return mean + torch.exp(lvar / 2) * eps.to(mean.device)
 
     def sample_z(self, n, device=None):

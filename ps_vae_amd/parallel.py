@@ -128,6 +128,8 @@ def make_reducer(model, group=None, always=False, overlap=None):
     on a GPU (`PSVAE_DP_OVERLAP=0` or `overlap=False` selects the single message after backward)."""
     import os
     model.flat_buffers()
+    if dist.is_available() and dist.is_initialized():
+        model.shard_rank = dist.get_rank(group)      # keys the epsilon rows of batches that carry no graph_base
     if overlap is None:
         overlap = os.environ.get('PSVAE_DP_OVERLAP', '1') != '0'
     if overlap and model.flat_buffers()[1].is_cuda:

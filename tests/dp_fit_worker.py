@@ -54,8 +54,11 @@ def main(out_path):
     reducer = make_reducer(model)    # the default: three gradient messages, two of them overlapped with backward
     assert isinstance(reducer, OverlappedReducer)
     history = fit(model, train, valid, max_epochs=EPOCHS, save_dir=out_path + '.ckpt', reducer=reducer)
+    draws = model.eps_draws
     z = model.get_z(train[0])        # a sampled latent: draws the epsilon of this rank's graphs of the global batch
-    torch.save({'params': model.flat_buffers()[0].detach().cpu(), 'history': history, 'z': z.cpu(),
+    mean, lvar = model.encode(train[0])
+    torch.save({'params': model.flat_buffers()[0].detach().cpu(), 'history': history, 'z': z.cpu(), 'draws': draws,
+                'mean': mean.cpu(), 'log_var': lvar.cpu(), 'graph_base': train[0]['_native'].graph_base,
                 'denoms': train[0]['_native'].denoms.cpu(), 'local_denoms': train[0]['_native'].local_denoms.cpu()},
                f'{out_path}.{rank}.pt')
     dist.barrier()

@@ -317,3 +317,36 @@ def test_scorer_fused_forward(S, n, B):
                                ('pair_in', 'h1', 'h2', 'h3', 'logits', 'row_loss', 'lse')):
         check_close(got, want, name, atol_scale=2e-5)
     assert torch.equal(out[0].cpu(), pin_ref)           # the gather copies bits
+
+
+@pytest.mark.parametrize('nseg,M,N,K,bias', [(4, 5000, 300, 300, True), (1, 24000, 328, 656, True), (1, 17000, 656, 328, False),
+                                             (2, 9000, 64, 200, True), (1, 16400, 600, 100, True), (1, 16384 + 7, 160, 160, True)])
+def test_weight_gradient_over_long_reductions(nseg, M, N, K, bias):
+    """dw = sum over segments of dy^T x (and db = column sums of dy) where the reduction runs over tens of
+    thousands of rows: the 160 x 160-tile kernel with its slab sum, against a float64 product."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    dy = torch.randn(nseg, M, N, device=dev(), generator=g)
+    x = torch.randn(nseg, M, K, device=dev(), generator=g)
+    dw = torch.full((N, K), float('nan'), device=dev())
+    db = torch.full((N,), float('nan'), device=dev()) if bias else None
+    nbytes = L.psvae_linear_scratch_bytes(M, N, K, nseg)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    seg_dy, seg_x = (M * N, M * K) if nseg > 1 else (0, 0)
+    _lib.check(L.psvae_linear_backward_weight(dy.data_ptr(), N, seg_dy, x.data_ptr(), K, seg_x, nseg, dw.data_ptr(),
+                                              db.data_ptr() if bias else None, M, N, K, scratch.data_ptr(), nbytes, st))
+    want = torch.einsum('smn,smk->nk', dy.double(), x.double()).float()
+    check_close(dw, want, 'dw', atol_scale=2e-5)
+    if bias:
+        check_close(db, dy.double().sum((0, 1)).float(), 'db', atol_scale=2e-5)
+    # reproducible bit for bit, also with a scratch buffer that only holds a few slabs
+    dw2 = torch.empty_like(dw)
+    _lib.check(L.psvae_linear_backward_weight(dy.data_ptr(), N, seg_dy, x.data_ptr(), K, seg_x, nseg, dw2.data_ptr(),
+                                              db.data_ptr() if bias else None, M, N, K, scratch.data_ptr(), nbytes, st))
+    assert torch.equal(dw, dw2)
+    small = min(nbytes, 3 * nseg * N * (K + 1) * 4 + 256)
+    _lib.check(L.psvae_linear_backward_weight(dy.data_ptr(), N, seg_dy, x.data_ptr(), K, seg_x, nseg, dw2.data_ptr(),
+                                              None, M, N, K, scratch.data_ptr(), small, st))
+    check_close(dw2, want, 'dw with a small scratch buffer', atol_scale=2e-5)

@@ -59,10 +59,18 @@ def test_fit_two_ranks_equals_the_undivided_batches(tmp_path):
     err = (got[0]['params'] - want).abs().max().item()
     assert err <= 2e-6, f'two-rank fit differs from the undivided steps by {err:.3e}'
     # the sampled latent of the two ranks' first batches = the sample one process draws for the 32 graphs together
+    # (under the ranks' own parameters: the 2e-6 allowed above would otherwise show in z)
+    with torch.no_grad():
+        model.flat_buffers()[0].copy_(got[0]['params'])
     for r in range(2):
+        assert got[r]['draws'] == draw and got[r]['graph_base'] == r * W.PER_RANK
+        mean, lvar = model.encode(batches[r][0])
+        assert torch.allclose(mean.cpu(), got[r]['mean'], rtol=1e-5, atol=1e-6), f'latent mean of rank {r}'
+        assert torch.allclose(lvar.cpu(), got[r]['log_var'], rtol=1e-5, atol=1e-6), f'latent log-variance of rank {r}'
         model.eps_draws = draw          # every draw advances the counter
         z = model.get_z(batches[r][0], eps=model.draw_eps(W.PER_RANK, r * W.PER_RANK))
-        assert torch.allclose(z.cpu(), got[r]['z'], rtol=1e-5, atol=1e-6), f'sampled z of rank {r}'
+        err = (z.cpu() - got[r]['z']).abs().max().item()
+        assert torch.allclose(z.cpu(), got[r]['z'], rtol=1e-5, atol=1e-6), f'sampled z of rank {r}: {err:.3e}'
     model.eps_draws = draw
     both = model.draw_eps(2 * W.PER_RANK, 0)
     model.eps_draws = draw
