@@ -184,7 +184,7 @@ def bulk_message_passing(dev, graphs=4096, H=300, iters=40):
             'plain_copy_same_rows': {'us': tc * 1e6, 'achieved': 2.0 * n * 4 * H / tc / 1e9, 'frac': 2.0 * n * 4 * H / tc / 1e9 / HBM_PEAK_GBS}}
 
 
-PMC_FILE = 'profiles/r01_pmc_traffic.json'
+PMC_FILE = 'profiles/r02_pmc_traffic.json'
 
 
 def pmc_traffic(kernel_class, args, per_gpu):

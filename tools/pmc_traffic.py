@@ -2,7 +2,7 @@
 """HBM traffic per launch and kernel class from two rocprofv3 --pmc passes of bench.py
 (FETCH_SIZE and WRITE_SIZE need separate passes: together they exceed the TCC counter slots).
 
-    tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+    tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [command] [workload]
 
 Both counters are in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced
 reads at 64 bytes, so the read side is doubled: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
@@ -19,6 +19,9 @@ CLASSES = [  # (substring of the kernel name, kernel class as bench.py reports i
     ('table_grad_', 'table_grad'), ('segment_pool_kernel', 'segment_pool'), ('pair_gather_kernel', 'pair_gather'),
     ('pair_scatter_kernel', 'pair_scatter'), ('gru_fwd', 'gru_forward'), ('gru_bwd', 'gru_backward'),
     ('softmax_ce_', 'softmax_ce'), ('sqnorm_partial_kernel', 'clip_adam'), ('clip_adam_kernel', 'clip_adam'),
+    ('gine_layer_fwd_kernel', 'gine_layer_fused'), ('gine_layer_bwd_kernel', 'gine_layer_fused'),
+    ('scorer_fwd_kernel', 'scorer_fused'), ('scorer_bwd_kernel', 'scorer_fused'), ('pack_weights_kernel', 'weight_pack'),
+    ('normal_rows_kernel', 'epsilon_draw'),
 ]
 
 
@@ -45,8 +48,10 @@ def main():
         out[cls] = {'launches_sampled': nf[cls], 'FETCH_SIZE_KiB_per_launch': f, 'WRITE_SIZE_KiB_per_launch': w,
                     'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0}
     json.dump({'formula': 'hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 read-side correction)',
-               'command': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bulk --profile-steps 1',
-               'workload': 'zinc, vocab 300, batch 128', 'classes': out}, open(sys.argv[3], 'w'), indent=1)
+               'command': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 ' + (sys.argv[4] if len(sys.argv) > 4 else
+                          'bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bulk --profile-steps 1 --config3-steps 0'),
+               'workload': sys.argv[5] if len(sys.argv) > 5 else 'zinc, vocab 300, batch 128', 'classes': out},
+              open(sys.argv[3], 'w'), indent=1)
     for k, v in out.items():
         print(f"{k:20s} {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB/launch  ({v['launches_sampled']} launches)")
 
