@@ -523,6 +523,24 @@ def main():
                             'frac': (mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mp_ms else None},
         'kernel_classes': table,
     }
+    if 'gine_layer_fused' in classes:
+        # aggregation fused into the MLP kernel: reported against max(HBM fraction, MFMA fraction), the HBM numerator
+        # being the aggregation's compulsory bytes 2 n 4H + 5 E + 4 (n + 1) per stack (encoder: all bonds, decoder-side
+        # stack: in-piece bonds).  Only when every launch of the class is a forward application (the fused backward of
+        # the MLPs, which larger batches add to the class, is no aggregation).
+        fms, fwork, fcnt = classes['gine_layer_fused']
+        sizes = [b['_native'].sizes for b in leg.batches]
+        t_layers = int(model._dims.t_enc)
+        H = int(model._dims.hidden)
+        agg_bytes = sum(2 * (2.0 * z['n'] * 4 * H + 4.0 * (z['n'] + 1)) + 5.0 * (z['E'] + z['E_in']) for z in sizes) / len(sizes)
+        if abs(fcnt / args.profile_steps - t_layers) < 0.5:
+            hbm = agg_bytes / (fms / fcnt * 1e-3) / 1e9
+            mf = fwork / (fms * 1e-3) / 1e12
+            out['fused_layer'] = {'kernel': 'gine_layer_fused', 'avg_launch_us': fms / fcnt * 1e3,
+                                  'mfma': {'achieved': mf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mf / MFMA_F32_PEAK_TF},
+                                  'hbm': {'achieved': hbm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm / HBM_PEAK_GBS,
+                                          'algorithmic_bytes_per_launch': agg_bytes},
+                                  'frac': max(mf / MFMA_F32_PEAK_TF, hbm / HBM_PEAK_GBS)}
     if strong_leg is not None:
         out['strong_scaling'] = strong_leg
     if single and not args.no_bulk:
