@@ -98,6 +98,49 @@ __device__ __forceinline__ Stage load_stage(const TileGeo& g, int r0, int tid) {
     return s;
 }
 
+// The same two loads with the address arithmetic taken off the vector ALU (aligned operands only).  What a thread
+// adds to the tile's origin - (row, column) of its two quads - never changes, and what changes from K-step to K-step
+// is uniform: the loads become "scalar base + 32-bit lane offset", the base advanced by scalar instructions.  A quad
+// outside the matrix points at the tile's origin (offset 0).  Only the one tile that overhangs the reduction range
+// needs other offsets (quads past the end redirected as well); they are prepared once and chosen by a uniform
+// select.  A tile that lies entirely past the range (fetched by the fixed-depth prefetch, never used) is read from
+// reduction index 0.  The bytes loaded are exactly those load_stage<T, true> loads.
+struct FastGeo { const char* tile0; long long step; unsigned off0, off1, offp0, offp1; int r_lim, r_part; };
+
+template <bool T>
+__device__ __forceinline__ FastGeo fast_geo(const TileGeo& g, int rbeg, int tid) {
+    FastGeo f;
+    f.tile0 = reinterpret_cast<const char*>(T ? g.X + g.o0 : g.X + (long long)g.o0 * g.ld);
+    f.step = T ? (long long)g.ld * 4 : 4;
+    f.r_lim = g.r_lim;
+    const int span = g.r_lim - rbeg, nk = (span + BK - 1) / BK;
+    f.r_part = (span % BK) ? rbeg + (nk - 1) * BK : -1;
+    const int lim_o = T ? (g.ones_col >= 0 ? g.ones_col : g.o_lim) : g.o_lim;
+    unsigned off[2], offp[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = tid + 256 * h;
+        const int dro = T ? ((q & 15) << 2) : (q >> 3);       // output index inside the tile
+        const int drr = T ? (q >> 4) : ((q & 7) << 2);        // reduction index inside the tile
+        const bool ok_o = g.o0 + dro < lim_o;
+        const unsigned o = (unsigned)(T ? drr * g.ld + dro : dro * g.ld + drr) * 4u;
+        off[h] = ok_o ? o : 0u;
+        offp[h] = (ok_o && f.r_part >= 0 && f.r_part + drr < g.r_lim) ? o : 0u;
+    }
+    f.off0 = off[0]; f.off1 = off[1]; f.offp0 = offp[0]; f.offp1 = offp[1];
+    return f;
+}
+
+__device__ __forceinline__ Stage fast_stage(const FastGeo& f, int r0) {
+    const char* sb = f.tile0 + (r0 < f.r_lim ? (long long)r0 * f.step : 0);
+    const bool part = r0 == f.r_part;
+    const unsigned o0 = part ? f.offp0 : f.off0, o1 = part ? f.offp1 : f.off1;
+    Stage s;
+    s.v0 = *reinterpret_cast<const float4*>(sb + o0);
+    s.v1 = *reinterpret_cast<const float4*>(sb + o1);
+    return s;
+}
+
 __device__ __forceinline__ float4 apply_flags(float4 v, unsigned flags) {
     v.x = (flags & 1u) ? v.x : 0.f; v.y = (flags & 2u) ? v.y : 0.f;
     v.z = (flags & 4u) ? v.z : 0.f; v.w = (flags & 8u) ? v.w : 0.f;
@@ -207,7 +250,8 @@ __device__ __forceinline__ void store_half(float (*s)[Pitch<T>::value], float4 v
 template <bool AT, bool BT, bool VEC, bool EDGE>
 __device__ __forceinline__ void kstep(const float (*cA)[Pitch<AT>::value], const float (*cB)[Pitch<BT>::value],
                                       float (*nA)[Pitch<AT>::value], float (*nB)[Pitch<BT>::value],
-                                      const TileGeo& ga, const TileGeo& gb, Stage& la, Stage& lb, int r_load,
+                                      const TileGeo& ga, const TileGeo& gb, const FastGeo& fga, const FastGeo& fgb,
+                                      Stage& la, Stage& lb, int r_load,
                                       const Stage& sa, const Stage& sb, int r_store, int arow, int brow, int kh, int tid,
                                       floatx16& acc) {
     float a0[4], b0[4], a1[4], b1[4];
@@ -218,10 +262,10 @@ __device__ __forceinline__ void kstep(const float (*cA)[Pitch<AT>::value], const
     PSVAE_READ(a0, b0, 0)
     PSVAE_SB();
     PSVAE_MFMA(a0[0], b0[0]);
-    la = load_stage<AT, VEC>(ga, r_load, tid);
+    la = VEC ? fast_stage(fga, r_load) : load_stage<AT, VEC>(ga, r_load, tid);
     PSVAE_SB();
     PSVAE_MFMA(a0[1], b0[1]);
-    lb = load_stage<BT, VEC>(gb, r_load, tid);
+    lb = VEC ? fast_stage(fgb, r_load) : load_stage<BT, VEC>(gb, r_load, tid);
     PSVAE_SB();
     PSVAE_MFMA(a0[2], b0[2]);
     PSVAE_READ(a1, b1, 1)
@@ -294,6 +338,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     if (nk > 0) {
         const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = lane >> 5;
         const TileGeo ga{A, p.lda, m0, p.M, rend, -1}, gb{B, p.ldb, n0, p.N, rend, p.ones_col};
+        const FastGeo fga = VEC ? fast_geo<AT>(ga, rbeg, tid) : FastGeo{}, fgb = VEC ? fast_geo<BT>(gb, rbeg, tid) : FastGeo{};
         // Four register stages, named so that every access is static.  Invariant at the top of a quad of K-steps
         // (kt a multiple of 4): LDS buffer 0 holds tile kt, stages 0/1/2 hold tiles kt+1/kt+2/kt+3 (loaded or in
         // flight), stage 3 is free.  Every K-step fetches the tile four steps ahead into the stage that has just
@@ -303,14 +348,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
         // has just issued): tiles past the end of the reduction range are fetched from a clamped address and,
         // if they are stored at all, stored as zeros.  The loop runs whole quads; the 0-3 K-steps left over
         // only consume stages that are already on their way, so their uniform branches contain no loads.
-        Stage a3 = load_stage<AT, VEC>(ga, rbeg, tid);
-        Stage b3 = load_stage<BT, VEC>(gb, rbeg, tid);
-        Stage a0 = load_stage<AT, VEC>(ga, rbeg + BK, tid);
-        Stage b0 = load_stage<BT, VEC>(gb, rbeg + BK, tid);
-        Stage a1 = load_stage<AT, VEC>(ga, rbeg + 2 * BK, tid);
-        Stage b1 = load_stage<BT, VEC>(gb, rbeg + 2 * BK, tid);
-        Stage a2 = load_stage<AT, VEC>(ga, rbeg + 3 * BK, tid);
-        Stage b2 = load_stage<BT, VEC>(gb, rbeg + 3 * BK, tid);
+        Stage a3 = (VEC ? fast_stage(fga, rbeg) : load_stage<AT, VEC>(ga, rbeg, tid));
+        Stage b3 = (VEC ? fast_stage(fgb, rbeg) : load_stage<BT, VEC>(gb, rbeg, tid));
+        Stage a0 = (VEC ? fast_stage(fga, rbeg + BK) : load_stage<AT, VEC>(ga, rbeg + BK, tid));
+        Stage b0 = (VEC ? fast_stage(fgb, rbeg + BK) : load_stage<BT, VEC>(gb, rbeg + BK, tid));
+        Stage a1 = (VEC ? fast_stage(fga, rbeg + 2 * BK) : load_stage<AT, VEC>(ga, rbeg + 2 * BK, tid));
+        Stage b1 = (VEC ? fast_stage(fgb, rbeg + 2 * BK) : load_stage<BT, VEC>(gb, rbeg + 2 * BK, tid));
+        Stage a2 = (VEC ? fast_stage(fga, rbeg + 3 * BK) : load_stage<AT, VEC>(ga, rbeg + 3 * BK, tid));
+        Stage b2 = (VEC ? fast_stage(fgb, rbeg + 3 * BK) : load_stage<BT, VEC>(gb, rbeg + 3 * BK, tid));
         store_stage<AT>(sA[0], a3, ga, rbeg, tid);
         store_stage<BT>(sB[0], b3, gb, rbeg, tid);
         __syncthreads();
@@ -319,40 +364,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
             for (int q = 0; q < nq; ++q) {
                 const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
                 if (r4 + BK <= rend) {
-                    kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
-                    kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
-                    kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
-                    kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, a2, b2, r4 + 3 * BK, a3, b3, r4, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, fga, fgb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, fga, fgb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[0], sB[0], sA[1], sB[1], ga, gb, fga, fgb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, false>(sA[1], sB[1], sA[0], sB[0], ga, gb, fga, fgb, a2, b2, r4 + 3 * BK, a3, b3, r4, arow, brow, kh, tid, acc);
                 } else {
-                    kstep<AT, BT, VEC, true>(sA[0], sB[0], sA[1], sB[1], ga, gb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
-                    kstep<AT, BT, VEC, true>(sA[1], sB[1], sA[0], sB[0], ga, gb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
-                    kstep<AT, BT, VEC, true>(sA[0], sB[0], sA[1], sB[1], ga, gb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
-                    kstep<AT, BT, VEC, true>(sA[1], sB[1], sA[0], sB[0], ga, gb, a2, b2, r4 + 3 * BK, a3, b3, r4, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[0], sB[0], sA[1], sB[1], ga, gb, fga, fgb, a3, b3, r4, a0, b0, r1, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[1], sB[1], sA[0], sB[0], ga, gb, fga, fgb, a0, b0, r4 + BK, a1, b1, r2, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[0], sB[0], sA[1], sB[1], ga, gb, fga, fgb, a1, b1, r4 + 2 * BK, a2, b2, r3, arow, brow, kh, tid, acc);
+                    kstep<AT, BT, VEC, true>(sA[1], sB[1], sA[0], sB[0], ga, gb, fga, fgb, a2, b2, r4 + 3 * BK, a3, b3, r4, arow, brow, kh, tid, acc);
                 }
             }
         } else {
             for (int q = 0; q < nq; ++q) {
                 const int r1 = rbeg + (4 * q + 1) * BK, r2 = r1 + BK, r3 = r2 + BK, r4 = r3 + BK;
-                a3 = load_stage<AT, VEC>(ga, r4, tid);
-                b3 = load_stage<BT, VEC>(gb, r4, tid);
+                a3 = (VEC ? fast_stage(fga, r4) : load_stage<AT, VEC>(ga, r4, tid));
+                b3 = (VEC ? fast_stage(fgb, r4) : load_stage<BT, VEC>(gb, r4, tid));
                 acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
                 store_stage<AT>(sA[1], a0, ga, r1, tid);
                 store_stage<BT>(sB[1], b0, gb, r1, tid);
                 __syncthreads();
-                a0 = load_stage<AT, VEC>(ga, r4 + BK, tid);
-                b0 = load_stage<BT, VEC>(gb, r4 + BK, tid);
+                a0 = (VEC ? fast_stage(fga, r4 + BK) : load_stage<AT, VEC>(ga, r4 + BK, tid));
+                b0 = (VEC ? fast_stage(fgb, r4 + BK) : load_stage<BT, VEC>(gb, r4 + BK, tid));
                 acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
                 store_stage<AT>(sA[0], a1, ga, r2, tid);
                 store_stage<BT>(sB[0], b1, gb, r2, tid);
                 __syncthreads();
-                a1 = load_stage<AT, VEC>(ga, r4 + 2 * BK, tid);
-                b1 = load_stage<BT, VEC>(gb, r4 + 2 * BK, tid);
+                a1 = (VEC ? fast_stage(fga, r4 + 2 * BK) : load_stage<AT, VEC>(ga, r4 + 2 * BK, tid));
+                b1 = (VEC ? fast_stage(fgb, r4 + 2 * BK) : load_stage<BT, VEC>(gb, r4 + 2 * BK, tid));
                 acc = tile_mfma(sA[0], sB[0], arow, brow, kh, acc);
                 store_stage<AT>(sA[1], a2, ga, r3, tid);
                 store_stage<BT>(sB[1], b2, gb, r3, tid);
                 __syncthreads();
-                a2 = load_stage<AT, VEC>(ga, r4 + 3 * BK, tid);
-                b2 = load_stage<BT, VEC>(gb, r4 + 3 * BK, tid);
+                a2 = (VEC ? fast_stage(fga, r4 + 3 * BK) : load_stage<AT, VEC>(ga, r4 + 3 * BK, tid));
+                b2 = (VEC ? fast_stage(fgb, r4 + 3 * BK) : load_stage<BT, VEC>(gb, r4 + 3 * BK, tid));
                 acc = tile_mfma(sA[1], sB[1], arow, brow, kh, acc);
                 store_stage<AT>(sA[0], a3, ga, r4, tid);
                 store_stage<BT>(sB[0], b3, gb, r4, tid);
