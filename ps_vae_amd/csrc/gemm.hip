@@ -103,19 +103,22 @@ __device__ __forceinline__ Stage load_stage(const TileGeo& g, int r0, int tid) {
 // is uniform: the loads become "scalar base + 32-bit lane offset", the base advanced by scalar instructions.  A quad
 // outside the matrix points at the tile's origin (offset 0).  Only the one tile that overhangs the reduction range
 // needs other offsets (quads past the end redirected as well); they are prepared once and chosen by a uniform
-// select.  A tile that lies entirely past the range (fetched by the fixed-depth prefetch, never used) is read from
-// reduction index 0.  The bytes loaded are exactly those load_stage<T, true> loads.
-struct FastGeo { const char* tile0; long long step; unsigned off0, off1, offp0, offp1; int r_lim, r_part; };
+// select.  A tile that lies entirely past the range (fetched by the fixed-depth prefetch, never used) is fetched as
+// the range's LAST tile once more - the only start index for which these lane offsets are known to stay inside the
+// matrix when the range is shorter than a tile.  Inside the range the bytes loaded are exactly those
+// load_stage<T, true> loads.
+struct FastGeo { const char* tile0; long long step; unsigned off0, off1, offp0, offp1; int r_last, r_part; };
 
 template <bool T>
 __device__ __forceinline__ FastGeo fast_geo(const TileGeo& g, int rbeg, int tid) {
     FastGeo f;
-    f.tile0 = reinterpret_cast<const char*>(T ? g.X + g.o0 : g.X + (long long)g.o0 * g.ld);
-    f.step = T ? (long long)g.ld * 4 : 4;
-    f.r_lim = g.r_lim;
-    const int span = g.r_lim - rbeg, nk = (span + BK - 1) / BK;
-    f.r_part = (span % BK) ? rbeg + (nk - 1) * BK : -1;
     const int lim_o = T ? (g.ones_col >= 0 ? g.ones_col : g.o_lim) : g.o_lim;
+    // (a tile that holds nothing but the ones column has no column of its own in the matrix: it reads column 0)
+    f.tile0 = reinterpret_cast<const char*>(T ? g.X + (g.o0 < lim_o ? g.o0 : 0) : g.X + (long long)g.o0 * g.ld);
+    f.step = T ? (long long)g.ld * 4 : 4;
+    const int span = g.r_lim - rbeg, nk = (span + BK - 1) / BK;
+    f.r_last = rbeg + (nk - 1) * BK;
+    f.r_part = (span % BK) ? f.r_last : -1;
     unsigned off[2], offp[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -132,8 +135,9 @@ __device__ __forceinline__ FastGeo fast_geo(const TileGeo& g, int rbeg, int tid)
 }
 
 __device__ __forceinline__ Stage fast_stage(const FastGeo& f, int r0) {
-    const char* sb = f.tile0 + (r0 < f.r_lim ? (long long)r0 * f.step : 0);
-    const bool part = r0 == f.r_part;
+    const int r = min(r0, f.r_last);
+    const char* sb = f.tile0 + (long long)r * f.step;
+    const bool part = r == f.r_part;
     const unsigned o0 = part ? f.offp0 : f.off0, o1 = part ? f.offp1 : f.off1;
     Stage s;
     s.v0 = *reinterpret_cast<const float4*>(sb + o0);

@@ -23,6 +23,9 @@ def _rand(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize('M,N,K,relu', [
     (2964, 300, 200, False), (2964, 300, 300, True), (128, 400, 1200, False), (128, 112, 400, False),
     (1, 5, 7, True), (67, 42, 16, False), (3000, 4, 656, False), (1408, 302, 200, False), (130, 66, 130, True),
+    # aligned operands whose reduction range is shorter than one 32-wide K-step in one of the three products (the
+    # prefetch then runs past the range from its first tile on): 1, 5, 6 and 20 rows, 4 and 8 input features
+    (1, 8, 8, False), (6, 400, 1200, False), (5, 300, 300, True), (20, 64, 4, False), (33, 128, 36, True), (64, 4, 4, False),
 ])
 def test_linear_forward_backward(M, N, K, relu):
     from ps_vae_amd import ops
