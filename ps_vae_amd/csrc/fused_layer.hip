@@ -137,20 +137,43 @@ template <int CT, int RT, bool RELU, bool ZERO_PAD>
 __device__ __forceinline__ void fl_store(const floatx4 (&acc)[RT][CT], const float (&bias)[CT], int N, float* img, int P, int col0,
                                          float* gout, size_t ldg, int row0, int nrows, int wave, int lane) {
     const int nl = lane & 15, kq = lane >> 4;
+    const bool full = row0 + 16 * RT <= nrows;      // uniform: every row of the tile exists (all tiles but the last)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int c = (wave * CT + ct) * 16 + nl;
+        const bool cok = c < N;
+        float v[RT][4];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = rt * 16 + 4 * kq + i;
-                float v = acc[rt][ct][i] + bias[ct];
-                if (RELU) v = fmaxf(v, 0.f);
-                if (c >= N) v = 0.f;
-                if (img && (c < N || (ZERO_PAD && col0 + c < P))) img[r * P + col0 + c] = v;
-                if (gout && c < N && row0 + r < nrows) gout[(size_t)(row0 + r) * ldg + col0 + c] = v;
+                float x = acc[rt][ct][i] + bias[ct];
+                if (RELU) x = fmaxf(x, 0.f);
+                v[rt][i] = cok ? x : 0.f;
             }
+        // one predicate per column tile instead of one per element
+        if (img && (cok || (ZERO_PAD && col0 + c < P))) {
+            float* q = img + (4 * kq) * P + col0 + c;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[(rt * 16 + i) * P] = v[rt][i];
+        }
+        if (gout && cok) {
+            float* q = gout + (size_t)(row0 + 4 * kq) * ldg + col0 + c;
+            if (full) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (row0 + rt * 16 + 4 * kq + i < nrows) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            }
+        }
     }
 }
 
@@ -305,18 +328,38 @@ __device__ __forceinline__ void fl_store_gated(const floatx4 (&acc)[RT][CT], con
             for (int i = 0; i < 4; ++i) gate[rt][ct][i] = act[(size_t)min(row0 + rt * 16 + 4 * kq + i, nrows - 1) * ldact + c];
     }
     if (SYNC) __syncthreads();
+    const bool full = row0 + 16 * RT <= nrows;      // uniform
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int c = (wave * CT + ct) * 16 + nl;
+        const bool cok = c < N;
+        float v[RT][4];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rt * 16 + 4 * kq + i;
-                const float v = (c < N && gate[rt][ct][i] > 0.f) ? acc[rt][ct][i] : 0.f;
-                if (c < P) img[r * P + c] = v;
-                if (c < N && row0 + r < nrows) gout[(size_t)(row0 + r) * ldg + c] = v;
+            for (int i = 0; i < 4; ++i) v[rt][i] = (cok && gate[rt][ct][i] > 0.f) ? acc[rt][ct][i] : 0.f;
+        if (c < P) {
+            float* q = img + (4 * kq) * P + c;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[(rt * 16 + i) * P] = v[rt][i];
+        }
+        if (cok) {
+            float* q = gout + (size_t)(row0 + 4 * kq) * ldg + c;
+            if (full) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (row0 + rt * 16 + 4 * kq + i < nrows) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
             }
+        }
     }
 }
 
