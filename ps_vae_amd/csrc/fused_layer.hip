@@ -56,9 +56,23 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
 
 // acc[rt][ct] += img[rows of tile rt][0 .. 16 KB) . W[columns of tile ct][same k], W packed as above.  RT 16-row
 // tiles per workgroup (image rows rt * 16 + (l & 15)), CT 16-column tiles per wave.
-template <int CT, int RT>
+// The weights of a product's first two blocks, requested ahead of the phase that precedes the product (they depend
+// on nothing the kernel computes): their L2 round trip then runs under that phase instead of in front of the
+// product's first MFMA.
+template <int CT>
+__device__ __forceinline__ void fl_prefetch(const float* __restrict__ Wp, int KB, int wave, int lane, float4 (&h0)[CT], float4 (&h1)[CT]) {
+    constexpr int Npad = 64 * CT;
+    const float* wlane = Wp + ((size_t)(lane >> 4) * Npad + wave * CT * 16 + (lane & 15)) * 4;
+    const float* p1 = wlane + (size_t)min(1, KB - 1) * (16 * Npad);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) h0[ct] = fl_ld4(wlane + ct * 64);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) h1[ct] = fl_ld4(p1 + ct * 64);
+}
+
+template <int CT, int RT, bool PRE = false>
 __device__ __forceinline__ void fl_product(const float* img, int P, const float* __restrict__ Wp, int KB, int wave, int lane,
-                                           floatx4 (&acc)[RT][CT]) {
+                                           floatx4 (&acc)[RT][CT], float4 (&b0)[CT], float4 (&b1)[CT]) {
     // (Every row's reduction runs in the same order wherever the row sits in the batch, so a graph's results do not
     // depend on its neighbours.  Starting each workgroup at a different block of the reduction, to keep the
     // workgroups from asking for the same lines of the matrix at the same moment, was measured and gains nothing.)
@@ -66,7 +80,7 @@ __device__ __forceinline__ void fl_product(const float* img, int P, const float*
     constexpr int Npad = 64 * CT;
     const float* wlane = Wp + ((size_t)kq * Npad + wave * CT * 16 + nl) * 4;      // + kb * 16 * Npad + ct * 64
     const float* arow = img + nl * P + 4 * kq;                                      // + rt * 16 * P + kb * 16
-    float4 b0[CT], b1[CT], b2[CT], a0[RT], a1[RT], a2[RT];
+    float4 b2[CT], a0[RT], a1[RT], a2[RT];
     // blocks past the last one are clamped to it (fetched, never used)
 #define FL_LOADB(B_, KB_)                                                                          \
     {                                                                                              \
@@ -94,9 +108,11 @@ __device__ __forceinline__ void fl_product(const float* img, int P, const float*
     // Stage s (registers a_s, b_s) holds block kb = s (mod 3).  Every block's weights are requested two blocks
     // ahead and its image rows one block ahead; the scheduling barriers keep the requests in program order, so that
     // each wait is for the oldest outstanding group only.
-    FL_LOADB(b0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    FL_LOADB(b1, 1)
+    if (!PRE) {
+        FL_LOADB(b0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        FL_LOADB(b1, 1)
+    }
     FL_READA(a0, 0)
     __builtin_amdgcn_sched_barrier(0);
     for (int kb = 0; kb < KB; kb += 3) {        // (the guards are uniform and hold no loads)
@@ -119,6 +135,13 @@ __device__ __forceinline__ void fl_product(const float* img, int P, const float*
 #undef FL_READA
 #undef FL_MFMA
 #undef FL_LOADB
+}
+
+template <int CT, int RT>
+__device__ __forceinline__ void fl_product(const float* img, int P, const float* __restrict__ Wp, int KB, int wave, int lane,
+                                           floatx4 (&acc)[RT][CT]) {
+    float4 b0[CT], b1[CT];
+    fl_product<CT, RT, false>(img, P, Wp, KB, wave, lane, acc, b0, b1);
 }
 
 template <int CT, int RT>
@@ -243,6 +266,8 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_fwd_kernel(const FLArgs
         for (int k = tid; k < FL_ROWS * padw; k += FL_THREADS) img[(k / padw) * P + H + (k % padw)] = 0.f;
     }
     __syncthreads();
+    float4 hb0[CT], hb1[CT];
+    fl_prefetch<CT>(g.w1p, KB, wave, lane, hb0, hb1);
     {
         const int items = FL_ROWS * H4;
         // two items per round: 2 x (own row + 4 neighbour rows) = 10 independent 16-byte loads in flight per thread
@@ -299,14 +324,15 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_fwd_kernel(const FLArgs
     // ---- phase 2: hid = relu(agg W1^T + b1), back into the image
     floatx4 acc[FL_RT][CT];
     fl_zero<CT, FL_RT>(acc);
-    fl_product<CT, FL_RT>(img, P, g.w1p, KB, wave, lane, acc);
+    fl_product<CT, FL_RT, true>(img, P, g.w1p, KB, wave, lane, acc, hb0, hb1);
+    fl_prefetch<CT>(g.w2p, KB, wave, lane, hb0, hb1);
     __syncthreads();            // every wave is done reading the aggregated image
     fl_store<CT, FL_RT, true, true>(acc, bias1, H, img, P, 0, SAVE ? g.hid : nullptr, H, row0, n, wave, lane);
     __syncthreads();
 
     // ---- phase 3: y = hid W2^T + b2
     fl_zero<CT, FL_RT>(acc);
-    fl_product<CT, FL_RT>(img, P, g.w2p, KB, wave, lane, acc);
+    fl_product<CT, FL_RT, true>(img, P, g.w2p, KB, wave, lane, acc, hb0, hb1);
     fl_store<CT, FL_RT, false, false>(acc, bias2, H, nullptr, 0, 0, g.y, a.ldy, row0, n, wave, lane);
 }
 
@@ -383,6 +409,8 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_kernel(const FLBArg
     const int per_xcd = gridDim.x / 8, bx = blockIdx.x;
     const int tile = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
     const int row0 = tile * FL_ROWS;
+    float4 hb0[CT], hb1[CT];
+    fl_prefetch<CT>(g.w2tp, KB, wave, lane, hb0, hb1);
     {   // the tile's rows of G, all loads of a thread first
         const int items = FL_ROWS * H4;
         for (int it = tid; it < items; it += 4 * FL_THREADS) {
@@ -407,11 +435,12 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_kernel(const FLBArg
     __syncthreads();
     floatx4 acc[FL_RT][CT];
     fl_zero<CT, FL_RT>(acc);
-    fl_product<CT, FL_RT>(img, P, g.w2tp, KB, wave, lane, acc);
+    fl_product<CT, FL_RT, true>(img, P, g.w2tp, KB, wave, lane, acc, hb0, hb1);
+    fl_prefetch<CT>(g.w1tp, KB, wave, lane, hb0, hb1);
     fl_store_gated<CT, FL_RT, true>(acc, g.hid, H, H, img, P, g.dh, H, row0, n, wave, lane);   // (barrier inside: G is no longer read)
     __syncthreads();
     fl_zero<CT, FL_RT>(acc);
-    fl_product<CT, FL_RT>(img, P, g.w1tp, KB, wave, lane, acc);
+    fl_product<CT, FL_RT, true>(img, P, g.w1tp, KB, wave, lane, acc, hb0, hb1);
     float nobias[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) nobias[ct] = 0.f;
