@@ -463,28 +463,29 @@ struct ScorerArgs {
     int S, H, Z, P, P2, PA, PB;
 };
 
-template <int CT>
+template <int CT, int RT>
 __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs a) {
+    constexpr int ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float fl_lds[];
-    __shared__ int s_src[16], s_dst[16], s_gr[16];
+    __shared__ int s_src[ROWS], s_dst[ROWS], s_gr[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * 16, S = a.S, H = a.H, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
-    float* imgA = fl_lds;              // [16][PA]: pair input, later s3
-    float* imgB = fl_lds + 16 * PA;    // [16][PB]: s1, then s2
+    const int row0 = blockIdx.x * ROWS, S = a.S, H = a.H, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
+    float* imgA = fl_lds;              // [ROWS][PA]: pair input, later s3
+    float* imgB = fl_lds + ROWS * PA;  // [ROWS][PB]: s1, then s2
     float bias0[CT], bias1[CT], bias2lo[CT], bias2hi[CT];
     fl_bias<CT>(a.b0, P2, wave, lane, bias0);
     fl_bias<CT>(a.b1, P2, wave, lane, bias1);
     fl_bias<CT>(a.b2, P2, wave, lane, bias2lo);
     fl_bias<CT>(a.b2 + P2, P2, wave, lane, bias2hi);
-    if (tid < 16) {
+    if (tid < ROWS) {
         const int sidx = min(row0 + tid, S - 1);
         s_src[tid] = a.src[sidx]; s_dst[tid] = a.dst[sidx]; s_gr[tid] = a.graph[sidx];
     }
-    for (int k = tid; k < 16 * (PA - P); k += FL_THREADS) imgA[(k / (PA - P)) * PA + P + k % (PA - P)] = 0.f;
-    for (int k = tid; k < 16 * (PB - P2); k += FL_THREADS) imgB[(k / (PB - P2)) * PB + P2 + k % (PB - P2)] = 0.f;
+    for (int k = tid; k < ROWS * (PA - P); k += FL_THREADS) imgA[(k / (PA - P)) * PA + P + k % (PA - P)] = 0.f;
+    for (int k = tid; k < ROWS * (PB - P2); k += FL_THREADS) imgB[(k / (PB - P2)) * PB + P2 + k % (PB - P2)] = 0.f;
     __syncthreads();
     {   // gather: four chunks per thread and round, all loads first
-        const int P4 = P >> 2, items = 16 * P4;
+        const int P4 = P >> 2, items = ROWS * P4;
         for (int it = tid; it < items; it += 4 * FL_THREADS) {
             float4 v[4];
             int rr[4], cc[4];
@@ -508,28 +509,29 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs
         }
     }
     __syncthreads();
-    floatx4 acc[1][CT];
+    floatx4 acc[RT][CT];
     // s1
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgA, PA, a.w0p, (P + 15) >> 4, wave, lane, acc);
-    fl_store<CT, 1, true, true>(acc, bias0, P2, imgB, PB, 0, a.s1, P2, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgA, PA, a.w0p, (P + 15) >> 4, wave, lane, acc);
+    fl_store<CT, RT, true, true>(acc, bias0, P2, imgB, PB, 0, a.s1, P2, row0, S, wave, lane);
     __syncthreads();
     // s2 (in place)
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w1p, (P2 + 15) >> 4, wave, lane, acc);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgB, PB, a.w1p, (P2 + 15) >> 4, wave, lane, acc);
     __syncthreads();
-    fl_store<CT, 1, true, true>(acc, bias1, P2, imgB, PB, 0, a.s2, P2, row0, S, wave, lane);
+    fl_store<CT, RT, true, true>(acc, bias1, P2, imgB, PB, 0, a.s2, P2, row0, S, wave, lane);
     __syncthreads();
     // s3, two halves, into the first image (the pair input is no longer needed)
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w2p_lo, (P2 + 15) >> 4, wave, lane, acc);
-    fl_store<CT, 1, false, false>(acc, bias2lo, P2, imgA, PA, 0, a.s3, P, row0, S, wave, lane);
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w2p_hi, (P2 + 15) >> 4, wave, lane, acc);
-    fl_store<CT, 1, false, false>(acc, bias2hi, P2, imgA, PA, P2, a.s3, P, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgB, PB, a.w2p_lo, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store<CT, RT, false, false>(acc, bias2lo, P2, imgA, PA, 0, a.s3, P, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgB, PB, a.w2p_hi, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store<CT, RT, false, false>(acc, bias2hi, P2, imgA, PA, P2, a.s3, P, row0, S, wave, lane);
     __syncthreads();
-    // head: wave w takes rows 4w .. 4w+3; lanes split the P columns in float4 chunks
-    {
+    // head: wave w takes rows 16h + 4w .. 16h + 4w+3 of every 16-row block h; lanes split the P columns in float4 chunks
+    for (int hb = 0; hb < RT; ++hb) {
+        const int rb = 16 * hb + 4 * wave;
         const int P4 = P >> 2;
         float part[4][4];
 #pragma unroll
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs
             for (int c = 0; c < 4; ++c) w[c] = fl_ld4(a.w3 + (size_t)c * P + ch * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 xv = *reinterpret_cast<const float4*>(imgA + (4 * wave + i) * PA + ch * 4);
+                const float4 xv = *reinterpret_cast<const float4*>(imgA + (rb + i) * PA + ch * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) part[i][c] += ((xv.x * w[c].x + xv.y * w[c].y) + xv.z * w[c].z) + xv.w * w[c].w;
             }
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) part[i][c] += __shfl_xor(part[i][c], o, 64);
         if (lane < 4) {
-            const int r = row0 + 4 * wave + lane;
+            const int r = row0 + rb + lane;
             if (r < S) {
                 float l[4];
 #pragma unroll
@@ -750,15 +752,21 @@ int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
     a.b0 = f.b0; a.b1 = f.b1; a.b2 = f.b2; a.w3 = f.w3; a.b3 = f.b3;
     a.pin = f.pin; a.s1 = f.s1; a.s2 = f.s2; a.s3 = f.s3; a.logits = f.logits; a.row_loss = f.row_loss; a.lse = f.lse;
     a.S = f.S; a.H = f.H; a.Z = f.Z; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
-    const size_t lds = (size_t)16 * (a.PA + a.PB) * sizeof(float);
+    // 32 pairs per workgroup (141 KB of LDS, one workgroup per CU): a streamed weight block then feeds twice the
+    // MFMAs of the 16-pair form (PSVAE_SCORER_ROWS=16 selects that one)
+    static const int rows = [] { const char* e = getenv("PSVAE_SCORER_ROWS"); return e && atoi(e) == 16 ? 16 : 32; }();
+    const size_t lds = (size_t)rows * (a.PA + a.PB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)scorer_fwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scorer_fwd_kernel<6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)scorer_fwd_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_set = true;
     }
+    if (lds > 156 * 1024) return PSVAE_E_SHAPE;
     ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P + 4.0 * P));
-    hipLaunchKernelGGL(scorer_fwd_kernel<6>, dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
+    if (rows == 16) hipLaunchKernelGGL((scorer_fwd_kernel<6, 1>), dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((scorer_fwd_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
