@@ -588,15 +588,16 @@ struct ScorerBwdArgs {
     int S, P, P2, PA, PB;
 };
 
-template <int CT>
+template <int CT, int RT>
 __global__ __launch_bounds__(FL_THREADS) void scorer_bwd_kernel(const ScorerBwdArgs a) {
+    constexpr int ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float fl_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * 16, S = a.S, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
-    float* imgA = fl_lds;              // [16][PA]: ds3
-    float* imgB = fl_lds + 16 * PA;    // [16][PB]: ds2, then ds1
+    const int row0 = blockIdx.x * ROWS, S = a.S, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
+    float* imgA = fl_lds;              // [ROWS][PA]: ds3
+    float* imgB = fl_lds + ROWS * PA;  // [ROWS][PB]: ds2, then ds1
     {
-        const int P4 = P >> 2, items = 16 * P4;
+        const int P4 = P >> 2, items = ROWS * P4;
         for (int it = tid; it < items; it += 4 * FL_THREADS) {
             float4 v[4];
 #pragma unroll
@@ -613,28 +614,28 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_bwd_kernel(const ScorerBwdA
                 *reinterpret_cast<float4*>(imgA + r * PA + c) = row0 + r < S ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        for (int k = tid; k < 16 * (PA - P); k += FL_THREADS) imgA[(k / (PA - P)) * PA + P + k % (PA - P)] = 0.f;
-        for (int k = tid; k < 16 * (PB - P2); k += FL_THREADS) imgB[(k / (PB - P2)) * PB + P2 + k % (PB - P2)] = 0.f;
+        for (int k = tid; k < ROWS * (PA - P); k += FL_THREADS) imgA[(k / (PA - P)) * PA + P + k % (PA - P)] = 0.f;
+        for (int k = tid; k < ROWS * (PB - P2); k += FL_THREADS) imgB[(k / (PB - P2)) * PB + P2 + k % (PB - P2)] = 0.f;
     }
     __syncthreads();
-    floatx4 acc[1][CT];
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgA, PA, a.w2tp, (P + 15) >> 4, wave, lane, acc);
-    fl_store_gated<CT, 1, false>(acc, a.s2, P2, P2, imgB, PB, a.ds2, P2, row0, S, wave, lane);
+    floatx4 acc[RT][CT];
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgA, PA, a.w2tp, (P + 15) >> 4, wave, lane, acc);
+    fl_store_gated<CT, RT, false>(acc, a.s2, P2, P2, imgB, PB, a.ds2, P2, row0, S, wave, lane);
     __syncthreads();
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w1tp, (P2 + 15) >> 4, wave, lane, acc);
-    fl_store_gated<CT, 1, true>(acc, a.s1, P2, P2, imgB, PB, a.ds1, P2, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgB, PB, a.w1tp, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store_gated<CT, RT, true>(acc, a.s1, P2, P2, imgB, PB, a.ds1, P2, row0, S, wave, lane);
     __syncthreads();
     float nobias[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) nobias[ct] = 0.f;
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w0tp_lo, (P2 + 15) >> 4, wave, lane, acc);
-    fl_store<CT, 1, false, false>(acc, nobias, P2, nullptr, 0, 0, a.dpin, P, row0, S, wave, lane);
-    fl_zero<CT, 1>(acc);
-    fl_product<CT, 1>(imgB, PB, a.w0tp_hi, (P2 + 15) >> 4, wave, lane, acc);
-    fl_store<CT, 1, false, false>(acc, nobias, P2, nullptr, 0, P2, a.dpin, P, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgB, PB, a.w0tp_lo, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store<CT, RT, false, false>(acc, nobias, P2, nullptr, 0, 0, a.dpin, P, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    fl_product<CT, RT>(imgB, PB, a.w0tp_hi, (P2 + 15) >> 4, wave, lane, acc);
+    fl_store<CT, RT, false, false>(acc, nobias, P2, nullptr, 0, P2, a.dpin, P, row0, S, wave, lane);
 }
 
 int fl_pitch(int K) {       // smallest pitch >= K rounded up to 16 with pitch = 8 mod 64
@@ -826,15 +827,19 @@ int scorer_bwd_fused(hipStream_t s, const ScorerBwd& f) {
     a.w0tp_hi = a.w0tp_lo + fused_pack_floats(P2, P2);
     a.ds2 = f.ds2; a.ds1 = f.ds1; a.dpin = f.dpin;
     a.S = f.S; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
-    const size_t lds = (size_t)16 * (a.PA + a.PB) * sizeof(float);
+    static const int rows = [] { const char* e = getenv("PSVAE_SCORER_ROWS"); return e && atoi(e) == 16 ? 16 : 32; }();
+    const size_t lds = (size_t)rows * (a.PA + a.PB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)scorer_bwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scorer_bwd_kernel<6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)scorer_bwd_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_set = true;
     }
+    if (lds > 156 * 1024) return PSVAE_E_SHAPE;
     ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P));
-    hipLaunchKernelGGL(scorer_bwd_kernel<6>, dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
+    if (rows == 16) hipLaunchKernelGGL((scorer_bwd_kernel<6, 1>), dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((scorer_bwd_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
