@@ -212,20 +212,26 @@ __device__ __forceinline__ unsigned long long granule(unsigned tag, float v) {
     return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 
-// One wave re-reads its `count` (<= N, wave-uniform, >= 1) exchange words, `stride` words apart, until every
-// one carries `tag`.  Gives up (returns false) when another wave has given up or after SPIN_LIMIT_TICKS.
-template <int N>
-__device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, unsigned tag, float (&v)[N], gu32* giveup,
-                                      gu32* sticky, int lane) {
+// One wave re-reads its exchange words until every one carries `tag`: `count` (<= N, wave-uniform, >= 1) words,
+// `stride` words apart, for each of `ntl` (<= RB, wave-uniform, >= 1) sequence tiles that lie `tile_stride` words
+// apart.  All RB * N loads of a round are in flight together (surplus slots repeat the last word / the last tile:
+// no branch around a load).  Gives up (returns false) when another wave has given up or after SPIN_LIMIT_TICKS.
+template <int N, int RB>
+__device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, long long tile_stride, int ntl, unsigned tag,
+                                      float (&v)[RB][N], gu32* giveup, gu32* sticky, int lane) {
     const unsigned long long t0 = wall_clock64();
     for (unsigned spins = 1;; ++spins) {
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int ii = i < count ? i : count - 1;     // surplus slots repeat the last word: no branch around a load
-            const unsigned long long x = __hip_atomic_load(first + ii * stride, RLX_AGENT);
-            v[i] = __uint_as_float((unsigned)x);
-            ok &= (unsigned)(x >> 32) == tag;
+        for (int rb = 0; rb < RB; ++rb) {
+            gu64* base = first + (rb < ntl ? rb : ntl - 1) * tile_stride;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int ii = i < count ? i : count - 1;
+                const unsigned long long x = __hip_atomic_load(base + ii * stride, RLX_AGENT);
+                v[rb][i] = __uint_as_float((unsigned)x);
+                ok &= (unsigned)(x >> 32) == tag;
+            }
         }
         if (__all(ok)) return true;
         if ((spins & 63u) == 0u) {
@@ -242,17 +248,19 @@ __device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, 
     }
 }
 
-// grid (hidden tiles, sequence-tile slots); block 256.  Thread (wave w, lane l) owns element
-// (row 4*(l>>4)+w, unit j0+(l&15)) of the tile for the gate arithmetic = register w of lane l in the MFMA
-// output layout, so the cross-wave K reduction reads LDS without bank conflicts.
+// grid (hidden tiles, sequence-group slots); block 256.  A workgroup steps RB sequence tiles of 16 sequences
+// each through time together (the W_hh slice in its registers serves all of them, and the cross-CU hop of a
+// time step is paid once for the RB tiles).  Thread (wave w, lane l) owns element (row 4*(l>>4)+w, unit
+// j0+(l&15)) of every tile for the gate arithmetic = register w of lane l in the MFMA output layout, so the
+// cross-wave K reduction reads LDS without bank conflicts.
 // Exchange buffer: [parity][sequence tile][k][16 rows] words; h_t carries tag t.
-template <int KSW>
+template <int KSW, int RB>
 __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
                                                            const float* __restrict__ whh, const float* __restrict__ bhh,
                                                            float* __restrict__ hseq, float* __restrict__ hprev,
                                                            float* __restrict__ gates, unsigned long long* exch_,
                                                            int B, int T, int R, int n_st, unsigned int* sticky_) {
-    __shared__ float red[2][4][3][4][64];
+    __shared__ float red[2][RB][4][3][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -279,78 +287,98 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
     if (tid == 0) s_fail = 0;
     __syncthreads();
     bool dead = false;
-    for (int st = blockIdx.y; st < n_st && !dead; st += gridDim.y) {
-        const int b0 = st * 16;
-        const int eb = b0 + erow, ebc = min(eb, B - 1);
-        const bool eok = uok && eb < B;
-        const int arow = min(b0 + j, B - 1);
-        const bool aok = b0 + j < B;
-        float hp = h0[(long long)ebc * R + euc];
-        if (!eok) hp = 0.f;
+    for (int st0 = blockIdx.y * RB; st0 < n_st && !dead; st0 += gridDim.y * RB) {
+        const int ntl = min(RB, n_st - st0);                       // live tiles of this group (uniform)
+        int ebc[RB], arow[RB];
+        bool eok[RB], aok[RB];
+        float hp[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int b0 = (st0 + rb) * 16, eb = b0 + erow;
+            ebc[rb] = min(eb, B - 1);
+            eok[rb] = uok && eb < B;
+            arow[rb] = min(b0 + j, B - 1);
+            aok[rb] = b0 + j < B;
+            const float v = h0[(long long)ebc[rb] * R + euc];
+            hp[rb] = eok[rb] ? v : 0.f;
+        }
         for (int t = 0; t < T; ++t) {
-            const float* g = gi + ((long long)ebc * T + t) * 3 * R + euc;
-            const float gir = g[0], giz = g[R], gin = g[2 * R];
-            float a[KSW];
+            float gir[RB], giz[RB], gin[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float* g = gi + ((long long)ebc[rb] * T + t) * 3 * R + euc;
+                gir[rb] = g[0]; giz[rb] = g[R]; gin[rb] = g[2 * R];
+            }
+            float a[RB][KSW];
             if (t == 0) {
 #pragma unroll
-                for (int i = 0; i < KSW; ++i) {
-                    const int k = min(4 * (wave + 4 * i) + kq, R - 1);
-                    const float v = h0[(long long)arow * R + k];
-                    a[i] = aok ? v : 0.f;
-                }
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int i = 0; i < KSW; ++i) {
+                        const int k = min(4 * (wave + 4 * i) + kq, R - 1);
+                        const float v = h0[(long long)arow[rb] * R + k];
+                        a[rb][i] = aok[rb] ? v : 0.f;
+                    }
             } else if (cnt > 0) {
-                gu64* first = exch + ((long long)((t & 1) * n_st + st) * R + 4 * wave + kq) * 16 + j;
-                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)t, a, giveup, sticky, lane)) s_fail = 1;
+                gu64* first = exch + ((long long)((t & 1) * n_st + st0) * R + 4 * wave + kq) * 16 + j;
+                if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)R * 16, ntl, (unsigned)t, a, giveup, sticky, lane)) s_fail = 1;
             }
-            floatx4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
 #pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wr[i], ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wz[i], az, 0, 0, 0);
-                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wn[i], an, 0, 0, 0);
-            }
-            float(*rd)[3][4][64] = red[t & 1];
+            for (int rb = 0; rb < RB; ++rb) {
+                floatx4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                rd[wave][0][reg][lane] = ar[reg];
-                rd[wave][1][reg][lane] = az[reg];
-                rd[wave][2][reg][lane] = an[reg];
+                for (int i = 0; i < KSW; ++i) {
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][i], wr[i], ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][i], wz[i], az, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][i], wn[i], an, 0, 0, 0);
+                }
+                float(*rd)[3][4][64] = red[t & 1][rb];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    rd[wave][0][reg][lane] = ar[reg];
+                    rd[wave][1][reg][lane] = az[reg];
+                    rd[wave][2][reg][lane] = an[reg];
+                }
             }
             __syncthreads();
             if (s_fail) { dead = true; break; }
-            const float ghr = rd[0][0][wave][lane] + rd[1][0][wave][lane] + rd[2][0][wave][lane] + rd[3][0][wave][lane];
-            const float ghz = rd[0][1][wave][lane] + rd[1][1][wave][lane] + rd[2][1][wave][lane] + rd[3][1][wave][lane];
-            const float ghn = rd[0][2][wave][lane] + rd[1][2][wave][lane] + rd[2][2][wave][lane] + rd[3][2][wave][lane] + cn;
-            const float r = sigmoidf_(gir + ghr + cr);
-            const float u = sigmoidf_(giz + ghz + cz);
-            const float c = tanhf(gin + r * ghn);
-            const float hn = eok ? (1.0f - u) * c + u * hp : 0.f;
-            if (uok && t + 1 < T)   // rows past the batch publish zeros: consumers sweep all 16 rows
-                __hip_atomic_store(exch + ((long long)(((t + 1) & 1) * n_st + st) * R + eunit) * 16 + erow,
-                                   granule((unsigned)(t + 1), hn), RLX_AGENT);
-            if (eok) {
-                const long long base = (long long)eb * T + t;
-                hseq[base * R + eunit] = hn;
-                hprev[base * R + eunit] = hp;
-                float* gs = gates + base * 4 * R;
-                gs[eunit] = r; gs[R + eunit] = u; gs[2 * R + eunit] = c; gs[3 * R + eunit] = ghn;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float(*rd)[3][4][64] = red[t & 1][rb];
+                const float ghr = rd[0][0][wave][lane] + rd[1][0][wave][lane] + rd[2][0][wave][lane] + rd[3][0][wave][lane];
+                const float ghz = rd[0][1][wave][lane] + rd[1][1][wave][lane] + rd[2][1][wave][lane] + rd[3][1][wave][lane];
+                const float ghn = rd[0][2][wave][lane] + rd[1][2][wave][lane] + rd[2][2][wave][lane] + rd[3][2][wave][lane] + cn;
+                const float r = sigmoidf_(gir[rb] + ghr + cr);
+                const float u = sigmoidf_(giz[rb] + ghz + cz);
+                const float c = tanhf(gin[rb] + r * ghn);
+                const float hn = eok[rb] ? (1.0f - u) * c + u * hp[rb] : 0.f;
+                if (uok && rb < ntl && t + 1 < T)   // rows past the batch publish zeros: consumers sweep all 16 rows
+                    __hip_atomic_store(exch + ((long long)(((t + 1) & 1) * n_st + st0 + rb) * R + eunit) * 16 + erow,
+                                       granule((unsigned)(t + 1), hn), RLX_AGENT);
+                if (eok[rb]) {
+                    const long long base = ((long long)(st0 + rb) * 16 + erow) * T + t;
+                    hseq[base * R + eunit] = hn;
+                    hprev[base * R + eunit] = hp[rb];
+                    float* gs = gates + base * 4 * R;
+                    gs[eunit] = r; gs[R + eunit] = u; gs[2 * R + eunit] = c; gs[3 * R + eunit] = ghn;
+                }
+                hp[rb] = hn;
             }
-            hp = hn;
         }
-        __syncthreads();   // the next sequence tile starts over on red[0]
+        __syncthreads();   // the next sequence group starts over on red[0]
     }
 }
 
-// Backward recurrence, same partition: a workgroup owns dL/dh of its 16 units.  Per step it turns that
-// into the three gate gradients, publishes them (tag = step count from the end), gathers the full
-// d(gh) row block [16 x 3R] and multiplies it with its 16 columns of W_hh.
-template <int KSW>
+// Backward recurrence, same partition: a workgroup owns dL/dh of its 16 units for RB sequence tiles.  Per step
+// it turns that into the three gate gradients, publishes them (tag = step count from the end), gathers the full
+// d(gh) row block [16 x 3R] of every tile and multiplies it with its 16 columns of W_hh.
+template <int KSW, int RB>
 __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restrict__ dhseq, const float* __restrict__ hprev,
                                                            const float* __restrict__ gates, const float* __restrict__ whh,
                                                            float* __restrict__ dgi, float* __restrict__ dgh,
                                                            float* __restrict__ dh0, unsigned long long* exch_,
                                                            int B, int T, int R, int n_st, unsigned int* sticky_) {
-    __shared__ float red[2][4][4][64];
+    __shared__ float red[2][RB][4][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -374,69 +402,105 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
     if (tid == 0) s_fail = 0;
     __syncthreads();
     bool dead = false;
-    for (int st = blockIdx.y; st < n_st && !dead; st += gridDim.y) {
-        const int b0 = st * 16;
-        const int eb = b0 + erow, ebc = min(eb, B - 1);
-        const bool eok = uok && eb < B;
-        float dh = 0.f;
-        // operands of the step are fetched one step ahead (plain loads of the forward pass's outputs)
-        long long base = (long long)ebc * T + (T - 1);
-        float n_d = dhseq[base * R + euc], n_hp = hprev[base * R + euc];
-        float n_r = gates[base * 4 * R + euc], n_z = gates[base * 4 * R + R + euc];
-        float n_c = gates[base * 4 * R + 2 * R + euc], n_g = gates[base * 4 * R + 3 * R + euc];
+    for (int st0 = blockIdx.y * RB; st0 < n_st && !dead; st0 += gridDim.y * RB) {
+        const int ntl = min(RB, n_st - st0);
+        int eb[RB], ebc[RB];
+        bool eok[RB];
+        float dh[RB], n_d[RB], n_hp[RB], n_r[RB], n_z[RB], n_c[RB], n_g[RB];
+        // operands of a step are fetched one step ahead (plain loads of the forward pass's outputs)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            eb[rb] = (st0 + rb) * 16 + erow; ebc[rb] = min(eb[rb], B - 1);
+            eok[rb] = uok && eb[rb] < B;
+            dh[rb] = 0.f;
+            const long long base = (long long)ebc[rb] * T + (T - 1);
+            n_d[rb] = dhseq[base * R + euc]; n_hp[rb] = hprev[base * R + euc];
+            n_r[rb] = gates[base * 4 * R + euc]; n_z[rb] = gates[base * 4 * R + R + euc];
+            n_c[rb] = gates[base * 4 * R + 2 * R + euc]; n_g[rb] = gates[base * 4 * R + 3 * R + euc];
+        }
         for (int t = T - 1, sidx = 0; t >= 0; --t, ++sidx) {
-            const float d = eok ? dh + n_d : 0.f;
-            const float r = n_r, z = n_z, c = n_c, ghn = n_g, hp = n_hp;
-            const float dpc = d * (1.0f - z) * (1.0f - c * c);
-            const float dpu = d * (hp - c) * z * (1.0f - z);
-            const float dghn = dpc * r;
-            const float dpr = dpc * ghn * r * (1.0f - r);
-            gu64* slab = exch + (long long)((sidx & 1) * n_st + st) * G * 16;
-            if (uok) {
-                const unsigned tag = (unsigned)(sidx + 1);
-                __hip_atomic_store(slab + (long long)eunit * 16 + erow, granule(tag, dpr), RLX_AGENT);
-                __hip_atomic_store(slab + (long long)(R + eunit) * 16 + erow, granule(tag, dpu), RLX_AGENT);
-                __hip_atomic_store(slab + (long long)(2 * R + eunit) * 16 + erow, granule(tag, dghn), RLX_AGENT);
-            }
-            if (eok) {
-                const long long bs = (long long)eb * T + t;
-                float* o1 = dgi + bs * G;
-                float* o2 = dgh + bs * G;
-                o1[eunit] = dpr; o1[R + eunit] = dpu; o1[2 * R + eunit] = dpc;
-                o2[eunit] = dpr; o2[R + eunit] = dpu; o2[2 * R + eunit] = dghn;
-            }
-            if (t > 0) {
-                base = (long long)ebc * T + (t - 1);
-                n_d = dhseq[base * R + euc]; n_hp = hprev[base * R + euc];
-                n_r = gates[base * 4 * R + euc]; n_z = gates[base * 4 * R + R + euc];
-                n_c = gates[base * 4 * R + 2 * R + euc]; n_g = gates[base * 4 * R + 3 * R + euc];
-            }
-            float a[KSW];
+            float dz_[RB];
 #pragma unroll
-            for (int i = 0; i < KSW; ++i) a[i] = 0.f;
+            for (int rb = 0; rb < RB; ++rb) {
+                const float d = eok[rb] ? dh[rb] + n_d[rb] : 0.f;
+                const float r = n_r[rb], z = n_z[rb], c = n_c[rb], ghn = n_g[rb], hp = n_hp[rb];
+                const float dpc = d * (1.0f - z) * (1.0f - c * c);
+                const float dpu = d * (hp - c) * z * (1.0f - z);
+                const float dghn = dpc * r;
+                const float dpr = dpc * ghn * r * (1.0f - r);
+                dz_[rb] = d * z;
+                gu64* slab = exch + (long long)((sidx & 1) * n_st + st0 + rb) * G * 16;
+                if (uok && rb < ntl) {
+                    const unsigned tag = (unsigned)(sidx + 1);
+                    __hip_atomic_store(slab + (long long)eunit * 16 + erow, granule(tag, dpr), RLX_AGENT);
+                    __hip_atomic_store(slab + (long long)(R + eunit) * 16 + erow, granule(tag, dpu), RLX_AGENT);
+                    __hip_atomic_store(slab + (long long)(2 * R + eunit) * 16 + erow, granule(tag, dghn), RLX_AGENT);
+                }
+                if (eok[rb]) {
+                    const long long bs = (long long)eb[rb] * T + t;
+                    float* o1 = dgi + bs * G;
+                    float* o2 = dgh + bs * G;
+                    o1[eunit] = dpr; o1[R + eunit] = dpu; o1[2 * R + eunit] = dpc;
+                    o2[eunit] = dpr; o2[R + eunit] = dpu; o2[2 * R + eunit] = dghn;
+                }
+                if (t > 0) {
+                    const long long base = (long long)ebc[rb] * T + (t - 1);
+                    n_d[rb] = dhseq[base * R + euc]; n_hp[rb] = hprev[base * R + euc];
+                    n_r[rb] = gates[base * 4 * R + euc]; n_z[rb] = gates[base * 4 * R + R + euc];
+                    n_c[rb] = gates[base * 4 * R + 2 * R + euc]; n_g[rb] = gates[base * 4 * R + 3 * R + euc];
+                }
+            }
+            float a[RB][KSW];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int i = 0; i < KSW; ++i) a[rb][i] = 0.f;
             if (cnt > 0) {
-                gu64* first = slab + (long long)(4 * wave + kq) * 16 + j;
-                if (!sweep<KSW>(first, 16 * 16, cnt, (unsigned)(sidx + 1), a, giveup, sticky, lane)) s_fail = 1;
+                gu64* first = exch + (long long)((sidx & 1) * n_st + st0) * G * 16 + (long long)(4 * wave + kq) * 16 + j;
+                if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)G * 16, ntl, (unsigned)(sidx + 1), a, giveup, sticky, lane)) s_fail = 1;
             }
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wb[i], acc, 0, 0, 0);
-            float(*rd)[4][64] = red[sidx & 1];
+            for (int rb = 0; rb < RB; ++rb) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) rd[wave][reg][lane] = acc[reg];
+                for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][i], wb[i], acc, 0, 0, 0);
+                float(*rd)[4][64] = red[sidx & 1][rb];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) rd[wave][reg][lane] = acc[reg];
+            }
             __syncthreads();
             if (s_fail) { dead = true; break; }
-            dh = rd[0][wave][lane] + rd[1][wave][lane] + rd[2][wave][lane] + rd[3][wave][lane] + d * z;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float(*rd)[4][64] = red[sidx & 1][rb];
+                dh[rb] = rd[0][wave][lane] + rd[1][wave][lane] + rd[2][wave][lane] + rd[3][wave][lane] + dz_[rb];
+            }
         }
-        if (eok && !dead) dh0[(long long)eb * R + eunit] = dh;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            if (eok[rb] && !dead) dh0[(long long)eb[rb] * R + eunit] = dh[rb];
         __syncthreads();
     }
 }
 
-int coop_slots(int ntile, int n_st) {
-    int slots = 240 / ntile;           // one workgroup per CU with headroom: every group stays resident
+// Sequence-group slots of a launch: one workgroup per CU with headroom, so that every group stays resident.
+int coop_slots(int ntile, int n_groups) {
+    int slots = 240 / ntile;
     if (slots < 1) slots = 1;
-    return slots < n_st ? slots : n_st;
+    return slots < n_groups ? slots : n_groups;
+}
+// Sequence tiles a workgroup steps together: the smallest of 1, 2, max_rb that brings all tiles of the batch
+// into one round of resident workgroups (a round costs T cross-CU hops whatever a workgroup carries, and the
+// spinning workgroups of every further round hold their CUs against the kernels of the other streams).
+// PSVAE_GRU_TILES=1/2/4 forces.
+int coop_tiles_per_group(int ntile, int n_st, int max_rb) {
+    static const int forced = [] { const char* e = getenv("PSVAE_GRU_TILES"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4) return forced < max_rb ? forced : max_rb;
+    int slots = 240 / ntile;
+    if (slots < 1) slots = 1;
+    int rb = 1;
+    while (rb < max_rb && (n_st + rb - 1) / rb > slots) rb *= 2;
+    return rb;
 }
 
 }  // namespace
@@ -447,11 +511,18 @@ size_t gru_exchange_bytes(int B, int T, int R) {
     return (size_t)EXCH_HEADER_WORDS * 8 + 2 * n_st * 3 * (size_t)R * ROWS * 8;
 }
 
+// Sequence tiles up to which the multi-CU kernels are the default.  Their workgroups each hold a compute unit's
+// registers for the whole recurrence (most of the time waiting for a hand-off), so beyond a few rounds of
+// resident groups they cost the kernels of the other streams more than the shorter recurrence gains: measured on
+// the training step, the multi-CU kernels win up to 640 sequences, tie at 768 and lose 5 % at 1024, 6 % at 2048.
+constexpr int COOP_MAX_TILES = 48;
+
 static bool coop_ok(int R, const void* exch, size_t exch_bytes, int B, int T) {
-    // PSVAE_GRU_MULTI_CU=0 forces the single-CU kernels (e.g. on a GPU that other processes keep busy:
-    // the multi-CU kernels need all workgroups of a sequence tile resident at the same time)
-    static const bool enabled = [] { const char* e = getenv("PSVAE_GRU_MULTI_CU"); return !(e && e[0] == '0'); }();
-    return enabled && exch && R % 4 == 0 && R >= 16 && R <= 256 && (reinterpret_cast<uintptr_t>(exch) & 15) == 0 &&
+    // PSVAE_GRU_MULTI_CU=0 forces the single-CU kernels (e.g. on a GPU that other processes keep busy: the
+    // multi-CU kernels need all workgroups of a sequence tile resident at the same time), =1 the multi-CU ones
+    static const int forced = [] { const char* e = getenv("PSVAE_GRU_MULTI_CU"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool wanted = forced >= 0 ? forced == 1 : (B + ROWS - 1) / ROWS <= COOP_MAX_TILES;
+    return wanted && exch && R % 4 == 0 && R >= 16 && R <= 256 && (reinterpret_cast<uintptr_t>(exch) & 15) == 0 &&
            exch_bytes >= gru_exchange_bytes(B, T, R);
 }
 
@@ -476,13 +547,14 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
             hipError_t e = hipMemsetAsync(exch, 0, used, s);
             if (e != hipSuccess) return (int)e;
         }
-        const dim3 grid(ntiles, coop_slots(ntiles, n_st));
-        if ((R >> 2) <= 52)
-            hipLaunchKernelGGL(gru_fwd_coop_kernel<13>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
-                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
-        else
-            hipLaunchKernelGGL(gru_fwd_coop_kernel<16>, grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
-                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
+        const bool narrow = (R >> 2) <= 52;     // wider rows keep more of W_hh per lane: registers for two tiles only
+        const int rb = coop_tiles_per_group(ntiles, n_st, narrow ? 4 : 2);
+        const dim3 grid(ntiles, coop_slots(ntiles, (n_st + rb - 1) / rb));
+#define PSVAE_GRU_FWD(KSW, RB) hipLaunchKernelGGL((gru_fwd_coop_kernel<KSW, RB>), grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, \
+                                                  gates, (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status)
+        if (narrow) { if (rb == 4) PSVAE_GRU_FWD(13, 4); else if (rb == 2) PSVAE_GRU_FWD(13, 2); else PSVAE_GRU_FWD(13, 1); }
+        else { if (rb == 2) PSVAE_GRU_FWD(16, 2); else PSVAE_GRU_FWD(16, 1); }
+#undef PSVAE_GRU_FWD
         PSVAE_LAUNCH_CHECK();
         return 0;
     }
@@ -509,13 +581,14 @@ int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* 
             hipError_t e = hipMemsetAsync(exch, 0, gru_exchange_bytes(B, T, R), s);
             if (e != hipSuccess) return (int)e;
         }
-        const dim3 grid(ntiles, coop_slots(ntiles, n_st));
-        if ((3 * R >> 2) <= 152)
-            hipLaunchKernelGGL(gru_bwd_coop_kernel<38>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,
-                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
-        else
-            hipLaunchKernelGGL(gru_bwd_coop_kernel<48>, grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, dgh, dh0,
-                               (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status);
+        const bool narrow = (3 * R >> 2) <= 152;
+        const int rb = coop_tiles_per_group(ntiles, n_st, narrow ? 2 : 1);
+        const dim3 grid(ntiles, coop_slots(ntiles, (n_st + rb - 1) / rb));
+#define PSVAE_GRU_BWD(KSW, RB) hipLaunchKernelGGL((gru_bwd_coop_kernel<KSW, RB>), grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, \
+                                                  dgh, dh0, (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status)
+        if (narrow) { if (rb == 2) PSVAE_GRU_BWD(38, 2); else PSVAE_GRU_BWD(38, 1); }
+        else PSVAE_GRU_BWD(48, 1);
+#undef PSVAE_GRU_BWD
         PSVAE_LAUNCH_CHECK();
         return 0;
     }

@@ -147,7 +147,11 @@ def test_segment_pool_forward_backward():
 
 @pytest.mark.parametrize('multi_cu', [False, True])
 @pytest.mark.parametrize('B,T,R', [(128, 11, 200), (5, 3, 16), (33, 1, 20), (16, 7, 64), (300, 9, 200), (47, 13, 256),
-                                   (700, 4, 24)])
+                                   (700, 4, 24),
+                                   # batches whose sequence tiles outnumber the resident workgroup groups: a workgroup
+                                   # steps 2 or 4 tiles together (last group ragged), wide rows take 2 at most;
+                                   # beyond 768 sequences the library takes the single-CU kernels by itself
+                                   (600, 6, 200), (750, 4, 200), (330, 4, 256), (1024, 3, 200)])
 def test_gru_forward_backward(B, T, R, multi_cu):
     from ps_vae_amd import _lib
     L = _lib.lib()
@@ -180,7 +184,7 @@ def test_gru_forward_backward(B, T, R, multi_cu):
     dgi, dgh, dh0 = torch.empty(B * T, 3 * R, device=d), torch.empty(B * T, 3 * R, device=d), torch.empty(B, R, device=d)
     _lib.check(L.psvae_gru_backward(g_dh.data_ptr(), hprev.data_ptr(), gates.data_ptr(), g_whh.data_ptr(), dgi.data_ptr(),
                                     dgh.data_ptr(), dh0.data_ptr(), B, T, R, xp, nx, st))
-    if multi_cu:
+    if multi_cu and (B + 15) // 16 <= 48:      # (larger batches run the single-CU kernels, which leave the buffer alone)
         assert int(exch[0]) == 0, 'a workgroup of the multi-CU recurrence gave up waiting'
     check_close(dgi.view(B, T, 3 * R), gir.grad, 'd gi')
     check_close(dh0, h0r.grad, 'd h0')
