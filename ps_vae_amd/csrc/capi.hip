@@ -81,7 +81,7 @@ extern "C" int psvae_gine_layer_forward(const float* x, int ldx, const int32_t* 
     if (scratch_bytes < psvae_gine_layer_scratch_bytes(H)) return PSVAE_E_WORKSPACE;
     float* w1p = (float*)scratch;
     float* w2p = w1p + fused_pack_floats(H, H);
-    const FusedPack pk[2] = {{w1, w1p, H, H, H, false}, {w2, w2p, H, H, H, false}};
+    const FusedPack pk[2] = {{w1, w1p, H, H, H, false, gine_layer_split(H)}, {w2, w2p, H, H, H, false, gine_layer_split(H)}};
     PSVAE_TRY(fused_pack((hipStream_t)stream, pk, 2));
     FusedLayerGroup g{x, rowptr, col ? col : rowptr, etype ? etype : rowptr, edge_w, edge_b, w1p, b1, w2p, b2, agg, hid, y,
                       one_plus_eps, 0};

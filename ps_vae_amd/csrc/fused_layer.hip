@@ -638,6 +638,431 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_bwd_kernel(const ScorerBwdA
     fl_store<CT, RT, false, false>(acc, nobias, P2, nullptr, 0, P2, a.dpin, P, row0, S, wave, lane);
 }
 
+// ===============================================================================================================
+// The same two kernels with the products on the bf16 matrix instruction (v_mfma_f32_16x16x32_bf16: 16 times the
+// rate of the fp32 one) at fp32 accuracy: every fp32 operand is cut into three bf16 pieces x = h + m + l, each the
+// round-to-nearest bf16 of what the pieces before it leave (|m| <= 2^-9 |x|, |l| <= 2^-18 |x|; the cut is EXACT:
+// three 8-bit significands with signs of their own cover the 24 bits), and a product a.b is the sum of the six
+// piece products down to 2^-18 of it  (hh) + (hm + mh) + (mm + hl + lh);  the three left out (ml, lm, ll) are
+// below 2^-26 |a||b| and of either sign, a quarter of the rounding a chain of fp32 fused multiply-adds makes at
+// every step.  Each
+// piece product is exact in fp32 and an instruction adds 32 of them into the fp32 accumulator, so a reduction of
+// length K rounds the accumulator 6 K / 32 times instead of K times.  Six instructions of 16 cycles replace eight
+// of 32 for the same 16 x 16 x 32 block.
+//
+// Operands: the weights are cut once per step by pack_weights_split_kernel into fragment order
+// [k / 32][piece][k quarter][column][8 bf16] (a lane's fragment is one 16-byte load, the 16 lanes of a quarter read
+// 256 contiguous bytes); the activations are cut as they are written into the LDS image, which holds three planes
+// [piece][row][pitch] of bf16 with a row pitch of an odd number of 16-byte units (conflict-free ds_read_b128 of
+// the fragments: lane l reads 8 consecutive k of row l & 15 at k quarter l >> 4).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf_bits(float x) {              // round to nearest even (v_cvt_pk_bf16_f32)
+    const __bf16 b = (__bf16)x;
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ void bf_cut(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = bf_bits(x);
+    const float r1 = x - __uint_as_float(h << 16);                 // exact: at most 16 significand bits, |r1| <= 2^-9 |x|
+    m = bf_bits(r1);
+    const float r2 = r1 - __uint_as_float(m << 16);                // exact: at most 7 significand bits, |r2| <= 2^-18 |x|
+    l = bf_bits(r2);                                               // exact
+}
+// four consecutive k of one row into the three planes (8 bytes each)
+__device__ __forceinline__ void bf_put4(char* img, int plane, int off, float4 v) {
+    unsigned h[4], m[4], l[4];
+    bf_cut(v.x, h[0], m[0], l[0]); bf_cut(v.y, h[1], m[1], l[1]); bf_cut(v.z, h[2], m[2], l[2]); bf_cut(v.w, h[3], m[3], l[3]);
+    *reinterpret_cast<uint2*>(img + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *reinterpret_cast<uint2*>(img + plane + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    *reinterpret_cast<uint2*>(img + 2 * plane + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+__device__ __forceinline__ void bf_put1(char* img, int plane, int off, float v) {
+    unsigned h, m, l;
+    bf_cut(v, h, m, l);
+    *reinterpret_cast<unsigned short*>(img + off) = (unsigned short)h;
+    *reinterpret_cast<unsigned short*>(img + plane + off) = (unsigned short)m;
+    *reinterpret_cast<unsigned short*>(img + 2 * plane + off) = (unsigned short)l;
+}
+
+struct PackSplitOne { const float* src; char* dst; int N, K, ld, transposed, Npad, KB; };
+struct PackSplitArgs { PackSplitOne m[8]; int count; };
+
+__global__ __launch_bounds__(256) void pack_weights_split_kernel(const PackSplitArgs a) {
+    const PackSplitOne& m = a.m[blockIdx.y];
+    const int total = m.KB * 4 * m.Npad;           // fragments: (k block, k quarter, column)
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int c = t % m.Npad, kq = (t / m.Npad) & 3, kb = t / (4 * m.Npad), k = kb * 32 + kq * 8;
+        unsigned h[8], mm[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = c < m.N && k + j < m.K;
+            const size_t idx = m.transposed ? (size_t)min(k + j, m.K - 1) * m.ld + min(c, m.N - 1)
+                                            : (size_t)min(c, m.N - 1) * m.ld + min(k + j, m.K - 1);
+            const float x = m.src[idx];
+            bf_cut(ok ? x : 0.f, h[j], mm[j], l[j]);
+        }
+        char* out = m.dst + (((size_t)kb * 3 * 4 + kq) * m.Npad + c) * 16;
+        const size_t pstride = (size_t)4 * m.Npad * 16;
+        *reinterpret_cast<uint4*>(out) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        *reinterpret_cast<uint4*>(out + pstride) = make_uint4(mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16));
+        *reinterpret_cast<uint4*>(out + 2 * pstride) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    }
+}
+
+__device__ __forceinline__ float4 fl_ld16(const char* p) { return *reinterpret_cast<const float4*>(p); }
+
+// blocks 0 and 1 of a product's weights, requested ahead of the phase in front of the product
+template <int CT>
+__device__ __forceinline__ void flb_prefetch(const char* __restrict__ Wp, int KB, int wave, int lane, float4 (&h0)[3][CT], float4 (&h1)[3][CT]) {
+    constexpr int Npad = 64 * CT;
+    const char* wlane = Wp + ((size_t)(lane >> 4) * Npad + wave * CT * 16 + (lane & 15)) * 16;
+    const char* p1 = wlane + (size_t)min(1, KB - 1) * (3 * 4 * Npad * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) h0[p][ct] = fl_ld16(wlane + ((size_t)p * 4 * Npad + ct * 16) * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) h1[p][ct] = fl_ld16(p1 + ((size_t)p * 4 * Npad + ct * 16) * 16);
+}
+
+// acc[rt][ct] += image rows of tile rt . W columns of tile ct over KB blocks of 32 reduction indices.  On entry
+// b0 / b1 hold (or have requested) the weights of blocks 0 / 1.  Every block's weights are requested a block and a
+// half ahead, its image rows half a block ahead.
+template <int CT, int RT>
+__device__ __forceinline__ void flb_product(const char* img, int PB, int plane, const char* __restrict__ Wp, int KB, int wave, int lane,
+                                            floatx4 (&acc)[RT][CT], float4 (&b0)[3][CT], float4 (&b1)[3][CT]) {
+    const int nl = lane & 15, kq = lane >> 4;
+    constexpr int Npad = 64 * CT;
+    const char* wlane = Wp + ((size_t)kq * Npad + wave * CT * 16 + nl) * 16;
+    const char* arow = img + nl * PB + kq * 16;
+    float4 a0[3][RT], a1[3][RT];
+#define FLB_LOADB(B_, KB_)                                                                                  \
+    {                                                                                                       \
+        const char* p_ = wlane + (size_t)min((KB_), KB - 1) * (3 * 4 * Npad * 16);                          \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                       \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                               \
+                B_[p][ct] = fl_ld16(p_ + ((size_t)p * 4 * Npad + ct * 16) * 16);                            \
+    }
+#define FLB_READA(A_, KB_)                                                                                  \
+    {                                                                                                       \
+        const int o_ = min((KB_), KB - 1) * 64;                                                             \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                       \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                               \
+                A_[p][rt] = *reinterpret_cast<const float4*>(arow + p * plane + rt * 16 * PB + o_);         \
+    }
+#define FLB_TERM(ACC_, A_, PA_, B_, PB_)                                                                    \
+    _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                       \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                   \
+            ACC_[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_[PA_][rt]), \
+                                                                   __builtin_bit_cast(bf16x8, B_[PB_][ct]), ACC_[rt][ct], 0, 0, 0);
+    // The instruction rounds its accumulator as it adds, at the accumulator's magnitude whatever the size of the
+    // terms: the five small products therefore go to an accumulator of their own (2^-9 of the main one, and so are
+    // its roundings) that joins the main one once, at the end - the main accumulator is rounded as often as a chain
+    // of fp32 multiply-adds rounds, not six times as often.
+    floatx4 lo[RT][CT];
+    fl_zero<CT, RT>(lo);
+#define FLB_MFMA(A_, B_)                                                                                    \
+    {                                                                                                       \
+        FLB_TERM(lo, A_, 2, B_, 0) FLB_TERM(lo, A_, 0, B_, 2) FLB_TERM(lo, A_, 1, B_, 1)                    \
+        FLB_TERM(lo, A_, 1, B_, 0) FLB_TERM(lo, A_, 0, B_, 1) FLB_TERM(acc, A_, 0, B_, 0)                   \
+    }
+    FLB_READA(a0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb = 0; kb < KB; kb += 2) {        // (the guards are uniform and hold no loads)
+        FLB_READA(a1, kb + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        FLB_MFMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        FLB_LOADB(b0, kb + 2)
+        FLB_READA(a0, kb + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < KB) FLB_MFMA(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        FLB_LOADB(b1, kb + 3)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += lo[rt][ct];
+#undef FLB_MFMA
+#undef FLB_TERM
+#undef FLB_READA
+#undef FLB_LOADB
+}
+
+// fl_store for a split image: the same values, cut into the three planes (2-byte stores)
+template <int CT, int RT, bool RELU, bool ZERO_PAD>
+__device__ __forceinline__ void flb_store(const floatx4 (&acc)[RT][CT], const float (&bias)[CT], int N, char* img, int PB, int plane,
+                                          int kpad, float* gout, size_t ldg, int row0, int nrows, int wave, int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+    const bool full = row0 + 16 * RT <= nrows;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = (wave * CT + ct) * 16 + nl;
+        const bool cok = c < N;
+        float v[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = acc[rt][ct][i] + bias[ct];
+                if (RELU) x = fmaxf(x, 0.f);
+                v[rt][i] = cok ? x : 0.f;
+            }
+        if (img && (cok || (ZERO_PAD && c < kpad))) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bf_put1(img, plane, (rt * 16 + 4 * kq + i) * PB + 2 * c, v[rt][i]);
+        }
+        if (gout && cok) {
+            float* q = gout + (size_t)(row0 + 4 * kq) * ldg + c;
+            if (full) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (row0 + rt * 16 + 4 * kq + i < nrows) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            }
+        }
+    }
+}
+
+template <int CT, int RT, bool SYNC>
+__device__ __forceinline__ void flb_store_gated(const floatx4 (&acc)[RT][CT], const float* __restrict__ act, size_t ldact, int N,
+                                                char* img, int PB, int plane, int kpad, float* gout, size_t ldg, int row0, int nrows,
+                                                int wave, int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+    float gate[RT][CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = min((wave * CT + ct) * 16 + nl, N - 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate[rt][ct][i] = act[(size_t)min(row0 + rt * 16 + 4 * kq + i, nrows - 1) * ldact + c];
+    }
+    if (SYNC) __syncthreads();
+    const bool full = row0 + 16 * RT <= nrows;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = (wave * CT + ct) * 16 + nl;
+        const bool cok = c < N;
+        float v[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[rt][i] = (cok && gate[rt][ct][i] > 0.f) ? acc[rt][ct][i] : 0.f;
+        if (c < kpad) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bf_put1(img, plane, (rt * 16 + 4 * kq + i) * PB + 2 * c, v[rt][i]);
+        }
+        if (cok) {
+            float* q = gout + (size_t)(row0 + 4 * kq) * ldg + c;
+            if (full) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (row0 + rt * 16 + 4 * kq + i < nrows) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
+            }
+        }
+    }
+}
+
+// P in FLArgs / FLBArgs: the image's row pitch in BYTES for these kernels
+// RT 16-row tiles per workgroup: 2 (32 nodes) while that already gives every compute unit a workgroup or more, 4
+// (64 nodes: a streamed weight block feeds twice the matrix instructions) for launches of several rounds.
+template <int CT, int RT, bool SAVE>
+__global__ __launch_bounds__(FL_THREADS) void gine_layer_fwd_split_kernel(const FLArgs a) {
+    constexpr int ROWS = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    __shared__ int s_e0[ROWS], s_deg[ROWS], s_nb[ROWS][FL_NB], s_ty[ROWS][FL_NB];
+    const FLGroup& g = a.g[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, PB = a.P, H4 = H >> 2, n = a.n, KB = (H + 31) >> 5, kpad = KB * 32;
+    const int plane = ROWS * PB;
+    char* img = reinterpret_cast<char*>(fl_lds);                    // [3][32][PB bytes]
+    float* etab = reinterpret_cast<float*>(img + 3 * plane);        // [5][H]
+    const int per_xcd = gridDim.x / 8, bx = blockIdx.x;
+    const int tile = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
+    const int row0 = tile * ROWS;
+    const float* __restrict__ x = g.x;
+    const char* w1p = reinterpret_cast<const char*>(g.w1p);
+    const char* w2p = reinterpret_cast<const char*>(g.w2p);
+    float bias1[CT], bias2[CT];
+    fl_bias<CT>(g.b1, H, wave, lane, bias1);
+    fl_bias<CT>(g.b2, H, wave, lane, bias2);
+
+    if (tid < ROWS) {
+        const int i = min(row0 + tid, n - 1);
+        const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+        const int deg = row0 + tid < n ? e1 - e0 : 0;
+        s_e0[tid] = e0; s_deg[tid] = deg;
+        const int E = g.rowptr[n], emax = max(E - 1, 0);
+        const int32_t* __restrict__ colp = E > 0 ? g.col : g.rowptr;
+        const int32_t* __restrict__ typ = E > 0 ? g.etype : g.rowptr;
+#pragma unroll
+        for (int k = 0; k < FL_NB; ++k) {
+            const int e = min(e0 + k, emax);
+            const int j = colp[e], t = typ[e] & 3;
+            s_nb[tid][k] = k < deg ? j : i;
+            s_ty[tid][k] = k < deg ? t : 4;
+        }
+    }
+    for (int k = tid; k < H; k += FL_THREADS) {
+        const float4 wk = fl_ld4(g.edge_w + (size_t)k * 4);
+        const float bk = g.edge_b[k];
+        etab[k] = wk.x + bk; etab[H + k] = wk.y + bk; etab[2 * H + k] = wk.z + bk; etab[3 * H + k] = wk.w + bk;
+        etab[4 * H + k] = -INFINITY;
+    }
+    {   // columns H .. kpad of every plane read as zeros in the products
+        const int padw = kpad - H;
+        for (int k = tid; k < 3 * ROWS * padw; k += FL_THREADS) {
+            const int p = k / (ROWS * padw), q = k - p * (ROWS * padw);
+            *reinterpret_cast<unsigned short*>(img + p * plane + (q / padw) * PB + 2 * (H + q % padw)) = 0;
+        }
+    }
+    __syncthreads();
+    float4 hb0[3][CT], hb1[3][CT];
+    flb_prefetch<CT>(w1p, KB, wave, lane, hb0, hb1);
+    {
+        const int items = ROWS * H4;
+        for (int it = tid; it < items; it += 2 * FL_THREADS) {
+            float4 acc2[2], own2[2];
+            int r2[2], c2[2];
+            float4 xs[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / H4, c = (t - r * H4) * 4;
+                r2[u] = r; c2[u] = c;
+                const int i = min(row0 + r, n - 1);
+                own2[u] = fl_ld4(x + (size_t)i * a.ldx + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xs[u][k] = fl_ld4(x + (size_t)s_nb[r][k] * a.ldx + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = r2[u], c = c2[u];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 e = *reinterpret_cast<const float4*>(etab + s_ty[r][k] * H + c);
+                    acc.x += fmaxf(xs[u][k].x + e.x, 0.f); acc.y += fmaxf(xs[u][k].y + e.y, 0.f);
+                    acc.z += fmaxf(xs[u][k].z + e.z, 0.f); acc.w += fmaxf(xs[u][k].w + e.w, 0.f);
+                }
+                const int deg = s_deg[r];
+                for (int k = 4; k < deg; ++k) {
+                    int j, t;
+                    if (k < FL_NB) { j = s_nb[r][k]; t = s_ty[r][k]; }
+                    else { const int e = s_e0[r] + k; j = g.col[e]; t = g.etype[e] & 3; }
+                    const float4 xv = fl_ld4(x + (size_t)j * a.ldx + c);
+                    const float4 e = *reinterpret_cast<const float4*>(etab + t * H + c);
+                    acc.x += fmaxf(xv.x + e.x, 0.f); acc.y += fmaxf(xv.y + e.y, 0.f);
+                    acc.z += fmaxf(xv.z + e.z, 0.f); acc.w += fmaxf(xv.w + e.w, 0.f);
+                }
+                acc2[u] = make_float4(acc.x + g.ope * own2[u].x, acc.y + g.ope * own2[u].y, acc.z + g.ope * own2[u].z,
+                                      acc.w + g.ope * own2[u].w);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (it + u * FL_THREADS >= items) continue;
+                const int r = r2[u], c = c2[u];
+                const bool live = row0 + r < n;
+                const float4 v = live ? acc2[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bf_put4(img, plane, r * PB + 2 * c, v);
+                if (SAVE && live) *reinterpret_cast<float4*>(g.agg + (size_t)(row0 + r) * H + c) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    floatx4 acc[RT][CT];
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img, PB, plane, w1p, KB, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w2p, KB, wave, lane, hb0, hb1);
+    __syncthreads();
+    flb_store<CT, RT, true, true>(acc, bias1, H, img, PB, plane, kpad, SAVE ? g.hid : nullptr, H, row0, n, wave, lane);
+    __syncthreads();
+
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img, PB, plane, w2p, KB, wave, lane, acc, hb0, hb1);
+    flb_store<CT, RT, false, false>(acc, bias2, H, nullptr, 0, 0, 0, g.y, a.ldy, row0, n, wave, lane);
+}
+
+template <int CT, int RT>
+__global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_split_kernel(const FLBArgs a) {
+    constexpr int ROWS = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    const FLBGroup& g = a.g[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, PB = a.P, H4 = H >> 2, n = a.n, KB = (H + 31) >> 5, kpad = KB * 32;
+    const int plane = ROWS * PB;
+    char* img = reinterpret_cast<char*>(fl_lds);
+    const char* w2tp = reinterpret_cast<const char*>(g.w2tp);
+    const char* w1tp = reinterpret_cast<const char*>(g.w1tp);
+    const int per_xcd = gridDim.x / 8, bx = blockIdx.x;
+    const int tile = bx < per_xcd * 8 ? (bx % 8) * per_xcd + bx / 8 : bx;
+    const int row0 = tile * ROWS;
+    float4 hb0[3][CT], hb1[3][CT];
+    flb_prefetch<CT>(w2tp, KB, wave, lane, hb0, hb1);
+    {
+        const int items = ROWS * H4;
+        for (int it = tid; it < items; it += 4 * FL_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / H4, c = (t - r * H4) * 4;
+                v[u] = fl_ld4(g.g + (size_t)min(row0 + r, n - 1) * H + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = it + u * FL_THREADS;
+                if (t >= items) continue;
+                const int r = t / H4, c = (t - r * H4) * 4;
+                bf_put4(img, plane, r * PB + 2 * c, row0 + r < n ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+        const int padw = kpad - H;
+        for (int k = tid; k < 3 * ROWS * padw; k += FL_THREADS) {
+            const int p = k / (ROWS * padw), q = k - p * (ROWS * padw);
+            *reinterpret_cast<unsigned short*>(img + p * plane + (q / padw) * PB + 2 * (H + q % padw)) = 0;
+        }
+    }
+    __syncthreads();
+    floatx4 acc[RT][CT];
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img, PB, plane, w2tp, KB, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w1tp, KB, wave, lane, hb0, hb1);
+    flb_store_gated<CT, RT, true>(acc, g.hid, H, H, img, PB, plane, kpad, g.dh, H, row0, n, wave, lane);
+    __syncthreads();
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img, PB, plane, w1tp, KB, wave, lane, acc, hb0, hb1);
+    float nobias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) nobias[ct] = 0.f;
+    flb_store<CT, RT, false, false>(acc, nobias, H, nullptr, 0, 0, 0, g.da, H, row0, n, wave, lane);
+}
+
+int flb_pitch_bytes(int K) { return (K + 31) / 32 * 64 + 16; }     // an odd number of 16-byte units
+
 int fl_pitch(int K) {       // smallest pitch >= K rounded up to 16 with pitch = 8 mod 64
     const int kp = (K + 15) / 16 * 16;
     return (kp - 8 + 63) / 64 * 64 + 8;
@@ -650,18 +1075,62 @@ static int fused_ct(int N) {          // the kernels' template value for N outpu
     return ct <= 5 ? 5 : (ct <= 6 ? 6 : 8);
 }
 
+// Nodes per workgroup of the cut-operand kernels: 64 once that still leaves every compute unit a round and a half
+// of workgroups (and the three planes of 64 rows fit the LDS), 32 below.  PSVAE_SPLIT_ROWS=32/64 forces.
+static int split_rows(int n, int ng, int H, size_t extra_lds) {
+    static const int forced = [] { const char* e = getenv("PSVAE_SPLIT_ROWS"); return e ? atoi(e) : 0; }();
+    const bool fits = (size_t)3 * 64 * flb_pitch_bytes(H) + extra_lds <= 156 * 1024;
+    if (forced == 32 || !fits) return 32;
+    if (forced == 64) return 64;
+    // one workgroup per compute unit at a time (registers): rounds of 256; a 64-node workgroup takes twice as long
+    // as a 32-node one and uses the weights it streams twice as well (measured: 64 wins at 256 and at 1024 graphs
+    // per step, loses at 128 and 512)
+    const long long r32 = ((long long)((n + 31) / 32) * ng + 255) / 256, r64 = 2 * (((long long)((n + 63) / 64) * ng + 255) / 256);
+    return r64 <= r32 ? 64 : 32;
+}
+
 bool gine_layer_fused_supported(int H, int ldx, int ldy) {
     return H % 4 == 0 && H >= 16 && H <= 512 && ldx % 4 == 0 && ldy >= H;
 }
 
-size_t fused_pack_floats(int N, int K) { return (size_t)((K + 15) / 16) * 16 * 64 * fused_ct(N); }
+// (room for either form of the packed matrix: fp32 fragments, or three bf16 planes per 32 reduction indices)
+size_t fused_pack_floats(int N, int K) {
+    const size_t npad = (size_t)64 * fused_ct(N);
+    return std::max((size_t)((K + 15) / 16) * 16 * npad, (size_t)((K + 31) / 32) * 48 * npad);
+}
+
+// Do the fused GINE kernels run their products on the bf16 matrix instruction over three-way cut operands (fp32
+// accuracy, see above)?  PSVAE_SPLIT_BF16=0 keeps the fp32 instruction.  Whoever packs the weights for
+// gine_layer_fwd / gine_layer_bwd must ask this and set FusedPack::split accordingly.
+bool gine_layer_split(int H) {
+    static const bool off = [] { const char* e = getenv("PSVAE_SPLIT_BF16"); return e && e[0] == '0'; }();
+    return !off && H >= 16 && H <= 512;
+}
 
 int fused_pack(hipStream_t s, const FusedPack* d, int count) {
     if (count < 1 || count > 8) return PSVAE_E_SHAPE;
+    if (d[0].split) {
+        PackSplitArgs b{};
+        b.count = count;
+        int most = 0;
+        for (int i = 0; i < count; ++i) {
+            if (!d[i].split) return PSVAE_E_SHAPE;          // one form per launch
+            if (!d[i].src || !d[i].dst) return PSVAE_E_NULL;
+            if (d[i].N < 1 || d[i].K < 1 || d[i].N > 512 || !aligned16(d[i].dst)) return PSVAE_E_SHAPE;
+            b.m[i] = PackSplitOne{d[i].src, reinterpret_cast<char*>(d[i].dst), d[i].N, d[i].K, d[i].ld, d[i].transposed ? 1 : 0,
+                                  64 * fused_ct(d[i].N), (d[i].K + 31) / 32};
+            most = std::max(most, b.m[i].KB * 4 * b.m[i].Npad);
+        }
+        ProfScope prof(s, KC_HEAD, 0);
+        hipLaunchKernelGGL(pack_weights_split_kernel, dim3((most + 255) / 256, count), dim3(256), 0, s, b);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
     PackArgs a{};
     a.count = count;
     int most = 0;
     for (int i = 0; i < count; ++i) {
+        if (d[i].split) return PSVAE_E_SHAPE;
         if (!d[i].src || !d[i].dst) return PSVAE_E_NULL;
         if (d[i].N < 1 || d[i].K < 1 || d[i].N > 512 || !aligned16(d[i].dst)) return PSVAE_E_SHAPE;
         a.m[i] = PackOne{d[i].src, d[i].dst, d[i].N, d[i].K, d[i].ld, d[i].transposed ? 1 : 0, 64 * fused_ct(d[i].N), (d[i].K + 15) / 16};
@@ -689,11 +1158,35 @@ int gine_layer_fwd(hipStream_t s, const FusedLayerGroup* grp, int ng, int ldx, i
         a.g[q] = FLGroup{f.x, f.rowptr, f.col, f.etype, f.edge_w, f.edge_b, f.w1p, f.b1, f.w2p, f.b2, f.agg, f.hid, f.y, f.ope};
         flops += 4.0 * n * H * H;
     }
-    a.n = n; a.H = H; a.P = fl_pitch(H); a.ldx = ldx; a.ldy = ldy;
-    const size_t lds = ((size_t)FL_ROWS * a.P + 5 * (size_t)H) * sizeof(float);
+    const bool split = gine_layer_split(H);
+    a.n = n; a.H = H; a.P = split ? flb_pitch_bytes(H) : fl_pitch(H); a.ldx = ldx; a.ldy = ldy;
+    const int rows = split ? split_rows(n, ng, H, 5 * (size_t)H * sizeof(float)) : FL_ROWS;
+    const size_t lds = split ? (size_t)3 * rows * a.P + 5 * (size_t)H * sizeof(float)
+                             : ((size_t)FL_ROWS * a.P + 5 * (size_t)H) * sizeof(float);
     const int CT = fused_ct(H);
-    const dim3 grid((n + FL_ROWS - 1) / FL_ROWS, ng);
+    const dim3 grid((n + rows - 1) / rows, ng);
     ProfScope prof(s, KC_GINE_LAYER, flops);
+#define FLS_LAUNCH2(CT_, RT_, SAVE_)                                                                                     \
+    do {                                                                                                                 \
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_fwd_split_kernel<CT_, RT_, SAVE_>,            \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+            return (int)hipGetLastError();                                                                               \
+        hipLaunchKernelGGL((gine_layer_fwd_split_kernel<CT_, RT_, SAVE_>), grid, dim3(FL_THREADS), lds, s, a);           \
+    } while (0)
+#define FLS_LAUNCH(CT_)                                                                                                  \
+    do {                                                                                                                 \
+        if (rows == 64) { if (save) FLS_LAUNCH2(CT_, 4, true); else FLS_LAUNCH2(CT_, 4, false); }                        \
+        else { if (save) FLS_LAUNCH2(CT_, 2, true); else FLS_LAUNCH2(CT_, 2, false); }                                   \
+    } while (0)
+    if (split) {
+        if (CT == 5) FLS_LAUNCH(5);
+        else if (CT == 6) FLS_LAUNCH(6);
+        else FLS_LAUNCH(8);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
+#undef FLS_LAUNCH
+#undef FLS_LAUNCH2
 #define FL_LAUNCH(CT_)                                                                                                   \
     do {                                                                                                                 \
         if (save) {                                                                                                      \
@@ -783,11 +1276,30 @@ int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, 
         if (!aligned16(f.g) || !aligned16(f.w2tp) || !aligned16(f.w1tp)) return PSVAE_E_ALIGN;
         a.g[q] = FLBGroup{f.g, f.hid, f.w2tp, f.w1tp, f.dh, f.da};
     }
-    a.n = n; a.H = H; a.P = fl_pitch(H);
-    const size_t lds = (size_t)FL_ROWS * a.P * sizeof(float);
+    const bool split = gine_layer_split(H);
+    a.n = n; a.H = H; a.P = split ? flb_pitch_bytes(H) : fl_pitch(H);
+    const int rows = split ? split_rows(n, ng, H, 0) : FL_ROWS;
+    const size_t lds = split ? (size_t)3 * rows * a.P : (size_t)FL_ROWS * a.P * sizeof(float);
     const int CT = fused_ct(H);
-    const dim3 grid((n + FL_ROWS - 1) / FL_ROWS, ng);
+    const dim3 grid((n + rows - 1) / rows, ng);
     ProfScope prof(s, KC_GINE_LAYER, 4.0 * n * H * H * ng);
+#define FLBS_LAUNCH2(CT_, RT_)                                                                                        \
+    do {                                                                                                              \
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_bwd_split_kernel<CT_, RT_>,                \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return (int)hipGetLastError();                                                                            \
+        hipLaunchKernelGGL((gine_layer_bwd_split_kernel<CT_, RT_>), grid, dim3(FL_THREADS), lds, s, a);               \
+    } while (0)
+#define FLBS_LAUNCH(CT_) do { if (rows == 64) FLBS_LAUNCH2(CT_, 4); else FLBS_LAUNCH2(CT_, 2); } while (0)
+    if (split) {
+        if (CT == 5) FLBS_LAUNCH(5);
+        else if (CT == 6) FLBS_LAUNCH(6);
+        else FLBS_LAUNCH(8);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
+#undef FLBS_LAUNCH
+#undef FLBS_LAUNCH2
 #define FLB_LAUNCH(CT_)                                                                                               \
     do {                                                                                                              \
         if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_bwd_kernel<CT_>,                           \

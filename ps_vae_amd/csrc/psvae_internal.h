@@ -111,7 +111,9 @@ struct FusedLayerBwdGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; 
 int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* g, int ngroups, int n, int H);
 // Weights as the fused kernels read them: a [N][K] matrix (row pitch ld; `transposed`: stored as [K][N]) re-laid as
 // [ceil(K/16)][4][Npad][4] so that a wave's operand fragment is four 256-byte runs; fused_pack_floats = its size.
-struct FusedPack { const float* src; float* dst; int N, K, ld; bool transposed; };
+// `split`: three bf16 planes per 32 reduction indices instead (the form the GINE kernels take when gine_layer_split(H) says so).
+struct FusedPack { const float* src; float* dst; int N, K, ld; bool transposed; bool split = false; };
+bool gine_layer_split(int H);
 size_t fused_pack_floats(int N, int K);
 int fused_pack(hipStream_t s, const FusedPack* d, int count);   // up to 8 matrices in one launch
 int gine_layer_fwd(hipStream_t s, const FusedLayerGroup* g, int ngroups, int ldx, int ldy, int n, int H, bool save);

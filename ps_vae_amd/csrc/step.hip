@@ -171,12 +171,15 @@ bool fused_scorer_fwd_on(int S) {
     const int m = fused_scorer_mode();
     return m == 1 || m == 2 || (m < 0 && S > 0 && (S + 31) / 32 <= 240);
 }
-// The fused backward of the GINE MLPs pays once a launch holds more row tiles than the GPU has compute units
-// (measured: -1.2 % at 128 graphs per step, +0.6 % at 256, +2.2 % at 512); PSVAE_FUSED_BWD=0 / 1 forces it off / on.
-bool fused_bwd_on(int n, int ng) {
+// The fused backward of the GINE MLPs.  On the fp32 matrix instruction it pays once a launch holds more row tiles
+// than the GPU has compute units (measured: -1.2 % at 128 graphs per step, +0.6 % at 256, +2.2 % at 512); on the
+// bf16 instruction over cut operands (gine_layer_split) its two products take half the time and it pays at every
+// size measured (+3 % at 128 graphs per step).  PSVAE_FUSED_BWD=0 / 1 forces it off / on.
+bool fused_bwd_on(int n, int ng, int H) {
     static const int forced = [] { const char* e = getenv("PSVAE_FUSED_BWD"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!fused_layers_on()) return false;
-    return forced >= 0 ? forced == 1 : (long long)((n + 31) / 32) * ng >= 320;
+    if (forced >= 0) return forced == 1;
+    return gine_layer_split(H) || (long long)((n + 31) / 32) * ng >= 320;
 }
 int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng, bool save = true, hipEvent_t packed = nullptr) {
     const int n = s.n, H = s.H, t = k[0].t;
@@ -197,8 +200,8 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
     } else if (fused) {    // the weights in the matrix cores' fragment order, once for all t applications
         FusedPack pk[4];
         for (int q = 0; q < ng; ++q) {
-            pk[2 * q] = FusedPack{k[q].w1, k[q].w1p, H, H, H, false};
-            pk[2 * q + 1] = FusedPack{k[q].w2, k[q].w2p, H, H, H, false};
+            pk[2 * q] = FusedPack{k[q].w1, k[q].w1p, H, H, H, false, gine_layer_split(H)};
+            pk[2 * q + 1] = FusedPack{k[q].w2, k[q].w2p, H, H, H, false, gine_layer_split(H)};
         }
         PSVAE_TRY(fused_pack(st, pk, 2 * ng));
     }
@@ -249,7 +252,7 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
     const size_t nH = (size_t)n * H, nblk = (size_t)gine_agg_bwd_blocks(n, H);
     const int64_t dG = ng == 2 ? k[1].Gr - k[0].Gr : 0, dDH = ng == 2 ? k[1].DH - k[0].DH : 0;
     const int64_t dDA = ng == 2 ? k[1].DA - k[0].DA : 0, dHid = ng == 2 ? k[1].Hid - k[0].Hid : 0;
-    const bool fused = fused_bwd_on(n, ng) && gine_layer_fused_supported(H, H, H);
+    const bool fused = fused_bwd_on(n, ng, H) && gine_layer_fused_supported(H, H, H);
     for (int l = t - 1; l >= 0; --l) {
         if (fused) {    // dHid_l = (G_{l+1} W2) * (Hid_l > 0) and dAgg_l = dHid_l W1 in one launch
             FusedLayerBwdGroup fg[2];
@@ -475,8 +478,8 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
             FusedPack pk[4];
             int cnt = 0;
             for (int q = dec_only ? 1 : 0; q < 2; ++q) {
-                pk[cnt++] = FusedPack{k[q].w1, k[q].w1p, s.H, s.H, s.H, false};
-                pk[cnt++] = FusedPack{k[q].w2, k[q].w2p, s.H, s.H, s.H, false};
+                pk[cnt++] = FusedPack{k[q].w1, k[q].w1p, s.H, s.H, s.H, false, gine_layer_split(s.H)};
+                pk[cnt++] = FusedPack{k[q].w2, k[q].w2p, s.H, s.H, s.H, false, gine_layer_split(s.H)};
             }
             PSVAE_TRY(fused_pack(s2, pk, cnt));
         }
@@ -555,14 +558,14 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     // lane 2 first: the GINE MLP weights in their transposed role, laid out for the fused backward kernel (the
     // dependent chain reaches the GINE stacks hundreds of microseconds later)
     const bool dec_only_ = b.conds != nullptr;
-    const bool fused_gine = fused_bwd_on(s.n, (dec_only_ || s.te != s.td) ? 1 : 2) && gine_layer_fused_supported(s.H, s.H, s.H);
+    const bool fused_gine = fused_bwd_on(s.n, (dec_only_ || s.te != s.td) ? 1 : 2, s.H) && gine_layer_fused_supported(s.H, s.H, s.H);
     if (fused_gine) {
         const Stack kk[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
         FusedPack pk[4];
         int cnt = 0;
         for (int q = dec_only_ ? 1 : 0; q < 2; ++q) {
-            pk[cnt++] = FusedPack{kk[q].w1, kk[q].w1tp, s.H, s.H, s.H, true};
-            pk[cnt++] = FusedPack{kk[q].w2, kk[q].w2tp, s.H, s.H, s.H, true};
+            pk[cnt++] = FusedPack{kk[q].w1, kk[q].w1tp, s.H, s.H, s.H, true, gine_layer_split(s.H)};
+            pk[cnt++] = FusedPack{kk[q].w2, kk[q].w2tp, s.H, s.H, s.H, true, gine_layer_split(s.H)};
         }
         PSVAE_TRY(fused_pack(s2, pk, cnt));
     }

@@ -239,7 +239,8 @@ def test_clip_adam_matches_torch():
 
 
 @pytest.mark.parametrize('n,E,H,save', [(2964, 6400, 300, True), (95, 160, 300, False), (33, 0, 64, True), (1, 0, 16, True),
-                                        (700, 5000, 512, True), (5000, 9000, 328, False), (40, 400, 20, True)])
+                                        (700, 5000, 512, True), (5000, 9000, 328, False), (40, 400, 20, True),
+                                        (24700, 52000, 300, True)])     # (enough row tiles for 64 nodes per workgroup)
 def test_gine_layer_fused_forward(n, E, H, save):
     """One GINE application in one launch (aggregation -> Linear + ReLU -> Linear) against plain fp32 torch; the
     copies of agg and hid it leaves for backward must equal the intermediate results; graphs with nodes of many
@@ -270,6 +271,18 @@ def test_gine_layer_fused_forward(n, E, H, save):
                                           hid.data_ptr() if save else None, y.data_ptr(), ldy, n, H, scratch.data_ptr(), nbytes, st))
     check_close(y[:, :H], y_ref, 'fused layer output')
     assert bool(torch.isnan(y[:, H:]).all()), 'columns past H of the output rows must stay untouched'
+    # fp32 accuracy: the products run on the bf16 matrix instruction over operands cut into three bf16 pieces; held to
+    # the float64 result, the output must be as close as plain fp32 arithmetic (torch on the CPU) gets, not merely
+    # within the comparison tolerance above
+    x6, w16, b16, w26, b26 = (t.double() for t in (x, w1, b1, w2, b2))
+    e6 = F.linear(F.one_hot(et, 4).double(), ew.double(), eb.double())
+    agg6 = torch.zeros_like(x6).index_add_(0, ei[1], torch.relu(x6.index_select(0, ei[0]) + e6)) + 1.5 * x6
+    y64 = F.linear(torch.relu(F.linear(agg6, w16, b16)), w26, b26)
+    scale = float(y64.abs().max())
+    err_gpu = float((y[:, :H].double().cpu() - y64).abs().max()) / scale
+    err_f32 = float((y_ref.double() - y64).abs().max()) / scale
+    print(f'fused layer n={n} H={H}: max error vs float64 / max|y|: GPU {err_gpu:.2e}, fp32 torch {err_f32:.2e}')
+    assert err_gpu <= 1.1 * err_f32 + 5e-8, (err_gpu, err_f32)
     if save:
         check_close(agg, agg_ref, 'saved aggregate')
         check_close(hid, hid_ref, 'saved hidden')
