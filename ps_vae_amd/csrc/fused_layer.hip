@@ -1062,6 +1062,203 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_split_kernel(const 
 }
 
 int flb_pitch_bytes(int K) { return (K + 31) / 32 * 64 + 16; }     // an odd number of 16-byte units
+// The link scorer's two kernels on cut operands.  ScorerArgs / ScorerBwdArgs as above with PA, PB = the split
+// images' row pitches in BYTES for reductions over P and P/2 and P3 = the pitch in floats of the fp32 image of s3
+// (which only the head reads).  The LDS regions are reused as the data in them dies: the pair input's planes
+// (reduction over P: 130 KB at 32 pairs) make way for s1's planes and later for s3; s2's planes sit behind them.
+template <int CT, int RT>
+__global__ __launch_bounds__(FL_THREADS) void scorer_fwd_split_kernel(const ScorerArgs a, int P3, int off2) {
+    constexpr int ROWS = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    __shared__ int s_src[ROWS], s_dst[ROWS], s_gr[ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS, S = a.S, H = a.H, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
+    const int KBA = (P + 31) >> 5, KBB = (P2 + 31) >> 5, kpadA = KBA * 32, kpadB = KBB * 32;
+    const int planeA = ROWS * PA, planeB = ROWS * PB;
+    char* base = reinterpret_cast<char*>(fl_lds);
+    char* img1 = base;                 // pair input planes, then s1 planes
+    char* img2 = base + off2;          // s2 planes
+    float* img3 = fl_lds;              // s3 as fp32 [ROWS][P3]
+    const char* w0p = reinterpret_cast<const char*>(a.w0p);
+    const char* w1p = reinterpret_cast<const char*>(a.w1p);
+    const char* w2lo = reinterpret_cast<const char*>(a.w2p_lo);
+    const char* w2hi = reinterpret_cast<const char*>(a.w2p_hi);
+    float bias0[CT], bias1[CT], bias2lo[CT], bias2hi[CT];
+    fl_bias<CT>(a.b0, P2, wave, lane, bias0);
+    fl_bias<CT>(a.b1, P2, wave, lane, bias1);
+    fl_bias<CT>(a.b2, P2, wave, lane, bias2lo);
+    fl_bias<CT>(a.b2 + P2, P2, wave, lane, bias2hi);
+    if (tid < ROWS) {
+        const int sidx = min(row0 + tid, S - 1);
+        s_src[tid] = a.src[sidx]; s_dst[tid] = a.dst[sidx]; s_gr[tid] = a.graph[sidx];
+    }
+    {
+        const int padw = kpadA - P;
+        for (int k = tid; k < 3 * ROWS * padw; k += FL_THREADS) {
+            const int p = k / (ROWS * padw), q = k - p * (ROWS * padw);
+            *reinterpret_cast<unsigned short*>(img1 + p * planeA + (q / padw) * PA + 2 * (P + q % padw)) = 0;
+        }
+    }
+    __syncthreads();
+    float4 hb0[3][CT], hb1[3][CT];
+    flb_prefetch<CT>(w0p, KBA, wave, lane, hb0, hb1);
+    {   // gather: four chunks per thread and round, all loads first
+        const int P4 = P >> 2, items = ROWS * P4;
+        for (int it = tid; it < items; it += 4 * FL_THREADS) {
+            float4 v[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / P4, c = (t - r * P4) * 4;
+                rr[u] = r; cc[u] = c;
+                const float* p = c < H ? a.emb + (size_t)s_src[r] * a.lde + c
+                                       : (c < 2 * H ? a.emb + (size_t)s_dst[r] * a.lde + (c - H) : a.z + (size_t)s_gr[r] * a.Z + (c - 2 * H));
+                v[u] = fl_ld4(p);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (it + u * FL_THREADS >= items) continue;
+                const bool live = row0 + rr[u] < S;
+                const float4 w = live ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bf_put4(img1, planeA, rr[u] * PA + 2 * cc[u], w);
+                if (live) *reinterpret_cast<float4*>(a.pin + (size_t)(row0 + rr[u]) * P + cc[u]) = w;
+            }
+        }
+    }
+    __syncthreads();
+    floatx4 acc[RT][CT];
+    // s1
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img1, PA, planeA, w0p, KBA, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w1p, KBB, wave, lane, hb0, hb1);
+    __syncthreads();            // the pair input is dead: its region takes s1
+    flb_store<CT, RT, true, true>(acc, bias0, P2, img1, PB, planeB, kpadB, a.s1, P2, row0, S, wave, lane);
+    __syncthreads();
+    // s2, behind s1
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img1, PB, planeB, w1p, KBB, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w2lo, KBB, wave, lane, hb0, hb1);
+    flb_store<CT, RT, true, true>(acc, bias1, P2, img2, PB, planeB, kpadB, a.s2, P2, row0, S, wave, lane);
+    __syncthreads();            // s1 is dead: its region takes s3 (fp32)
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img2, PB, planeB, w2lo, KBB, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w2hi, KBB, wave, lane, hb0, hb1);
+    fl_store<CT, RT, false, false>(acc, bias2lo, P2, img3, P3, 0, a.s3, P, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img2, PB, planeB, w2hi, KBB, wave, lane, acc, hb0, hb1);
+    fl_store<CT, RT, false, false>(acc, bias2hi, P2, img3, P3, P2, a.s3, P, row0, S, wave, lane);
+    __syncthreads();
+    // head: wave w takes rows 16h + 4w .. 16h + 4w+3 of every 16-row block h; lanes split the P columns in float4 chunks
+    for (int hb = 0; hb < RT; ++hb) {
+        const int rb = 16 * hb + 4 * wave;
+        const int P4 = P >> 2;
+        float part[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[i][c] = 0.f;
+        for (int ch = lane; ch < P4; ch += 64) {
+            float4 w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = fl_ld4(a.w3 + (size_t)c * P + ch * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 xv = *reinterpret_cast<const float4*>(img3 + (rb + i) * P3 + ch * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) part[i][c] += ((xv.x * w[c].x + xv.y * w[c].y) + xv.z * w[c].z) + xv.w * w[c].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part[i][c] += __shfl_xor(part[i][c], o, 64);
+        if (lane < 4) {
+            const int r = row0 + rb + lane;
+            if (r < S) {
+                float l[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = lane == 0 ? part[0][c] : (lane == 1 ? part[1][c] : (lane == 2 ? part[2][c] : part[3][c]));
+                    l[c] = v + a.b3[c];
+                }
+                const float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+                const float lse = mx + logf(((expf(l[0] - mx) + expf(l[1] - mx)) + expf(l[2] - mx)) + expf(l[3] - mx));
+                const int tg = a.gold[r];
+                reinterpret_cast<float4*>(a.logits)[r] = make_float4(l[0], l[1], l[2], l[3]);
+                a.lse[r] = lse;
+                a.row_loss[r] = lse - (tg == 0 ? l[0] : (tg == 1 ? l[1] : (tg == 2 ? l[2] : l[3])));
+            }
+        }
+    }
+}
+
+template <int CT, int RT>
+__global__ __launch_bounds__(FL_THREADS) void scorer_bwd_split_kernel(const ScorerBwdArgs a, int off2) {
+    constexpr int ROWS = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS, S = a.S, P = a.P, P2 = a.P2, PA = a.PA, PB = a.PB;
+    const int KBA = (P + 31) >> 5, KBB = (P2 + 31) >> 5, kpadA = KBA * 32, kpadB = KBB * 32;
+    const int planeA = ROWS * PA, planeB = ROWS * PB;
+    char* img1 = reinterpret_cast<char*>(fl_lds);          // ds3 planes, then ds2 planes
+    char* img2 = img1 + off2;                              // ds1 planes
+    const char* w2tp = reinterpret_cast<const char*>(a.w2tp);
+    const char* w1tp = reinterpret_cast<const char*>(a.w1tp);
+    const char* w0lo = reinterpret_cast<const char*>(a.w0tp_lo);
+    const char* w0hi = reinterpret_cast<const char*>(a.w0tp_hi);
+    float4 hb0[3][CT], hb1[3][CT];
+    flb_prefetch<CT>(w2tp, KBA, wave, lane, hb0, hb1);
+    {
+        const int P4 = P >> 2, items = ROWS * P4;
+        for (int it = tid; it < items; it += 4 * FL_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(it + u * FL_THREADS, items - 1);
+                const int r = t / P4, c = (t - r * P4) * 4;
+                v[u] = fl_ld4(a.ds3 + (size_t)min(row0 + r, S - 1) * P + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = it + u * FL_THREADS;
+                if (t >= items) continue;
+                const int r = t / P4, c = (t - r * P4) * 4;
+                bf_put4(img1, planeA, r * PA + 2 * c, row0 + r < S ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+        const int padw = kpadA - P;
+        for (int k = tid; k < 3 * ROWS * padw; k += FL_THREADS) {
+            const int p = k / (ROWS * padw), q = k - p * (ROWS * padw);
+            *reinterpret_cast<unsigned short*>(img1 + p * planeA + (q / padw) * PA + 2 * (P + q % padw)) = 0;
+        }
+    }
+    __syncthreads();
+    floatx4 acc[RT][CT];
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img1, PA, planeA, w2tp, KBA, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w1tp, KBB, wave, lane, hb0, hb1);
+    flb_store_gated<CT, RT, true>(acc, a.s2, P2, P2, img1, PB, planeB, kpadB, a.ds2, P2, row0, S, wave, lane);   // (barrier inside: ds3 is dead)
+    __syncthreads();
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img1, PB, planeB, w1tp, KBB, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w0lo, KBB, wave, lane, hb0, hb1);
+    flb_store_gated<CT, RT, false>(acc, a.s1, P2, P2, img2, PB, planeB, kpadB, a.ds1, P2, row0, S, wave, lane);  // behind ds2
+    __syncthreads();
+    float nobias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) nobias[ct] = 0.f;
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img2, PB, planeB, w0lo, KBB, wave, lane, acc, hb0, hb1);
+    flb_prefetch<CT>(w0hi, KBB, wave, lane, hb0, hb1);
+    fl_store<CT, RT, false, false>(acc, nobias, P2, nullptr, 0, 0, a.dpin, P, row0, S, wave, lane);
+    fl_zero<CT, RT>(acc);
+    flb_product<CT, RT>(img2, PB, planeB, w0hi, KBB, wave, lane, acc, hb0, hb1);
+    fl_store<CT, RT, false, false>(acc, nobias, P2, nullptr, 0, P2, a.dpin, P, row0, S, wave, lane);
+}
+
 
 int fl_pitch(int K) {       // smallest pitch >= K rounded up to 16 with pitch = 8 mod 64
     const int kp = (K + 15) / 16 * 16;
@@ -1226,8 +1423,9 @@ int scorer_pack(hipStream_t s, const float* w0, const float* w1, const float* w2
     float* w1p = w0p + fused_pack_floats(P2, P);
     float* w2lo = w1p + fused_pack_floats(P2, P2);
     float* w2hi = w2lo + fused_pack_floats(P2, P2);
-    const FusedPack pk[4] = {{w0, w0p, P2, P, P, false}, {w1, w1p, P2, P2, P2, false}, {w2, w2lo, P2, P2, P2, false},
-                             {w2 + (size_t)P2 * P2, w2hi, P2, P2, P2, false}};
+    const bool sp = gine_layer_split(H);
+    const FusedPack pk[4] = {{w0, w0p, P2, P, P, false, sp}, {w1, w1p, P2, P2, P2, false, sp}, {w2, w2lo, P2, P2, P2, false, sp},
+                             {w2 + (size_t)P2 * P2, w2hi, P2, P2, P2, false, sp}};
     return fused_pack(s, pk, 4);
 }
 
@@ -1249,6 +1447,23 @@ int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
     // 32 pairs per workgroup (141 KB of LDS, one workgroup per CU): a streamed weight block then feeds twice the
     // MFMAs of the 16-pair form (PSVAE_SCORER_ROWS=16 selects that one)
     static const int rows = [] { const char* e = getenv("PSVAE_SCORER_ROWS"); return e && atoi(e) == 16 ? 16 : 32; }();
+    if (gine_layer_split(f.H)) {        // products on the bf16 matrix instruction over cut operands (weights packed to match)
+        a.PA = flb_pitch_bytes(P); a.PB = flb_pitch_bytes(P2);
+        const int P3 = P + 4;
+        const size_t planes2 = (size_t)3 * 32 * a.PB, off2 = (std::max(planes2, (size_t)32 * P3 * sizeof(float)) + 255) / 256 * 256;
+        const size_t lds = std::max((size_t)3 * 32 * a.PA, off2 + planes2);
+        static bool split_attr_set = false;
+        if (!split_attr_set) {
+            if (hipFuncSetAttribute((const void*)scorer_fwd_split_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
+                return (int)hipGetLastError();
+            split_attr_set = true;
+        }
+        if (lds > 159 * 1024) return PSVAE_E_SHAPE;
+        ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P + 4.0 * P));
+        hipLaunchKernelGGL((scorer_fwd_split_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a, P3, (int)off2);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)rows * (a.PA + a.PB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1322,8 +1537,9 @@ int scorer_pack_bwd(hipStream_t s, const float* w0, const float* w1, const float
     float* w1tp = w2tp + fused_pack_floats(P2, P);
     float* w0lo = w1tp + fused_pack_floats(P2, P2);
     float* w0hi = w0lo + fused_pack_floats(P2, P2);
-    const FusedPack pk[4] = {{w2, w2tp, P2, P, P2, true}, {w1, w1tp, P2, P2, P2, true}, {w0, w0lo, P2, P2, P, true},
-                             {w0 + P2, w0hi, P2, P2, P, true}};
+    const bool sp = gine_layer_split(H);
+    const FusedPack pk[4] = {{w2, w2tp, P2, P, P2, true, sp}, {w1, w1tp, P2, P2, P2, true, sp}, {w0, w0lo, P2, P2, P, true, sp},
+                             {w0 + P2, w0hi, P2, P2, P, true, sp}};
     return fused_pack(s, pk, 4);
 }
 
@@ -1340,6 +1556,22 @@ int scorer_bwd_fused(hipStream_t s, const ScorerBwd& f) {
     a.ds2 = f.ds2; a.ds1 = f.ds1; a.dpin = f.dpin;
     a.S = f.S; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
     static const int rows = [] { const char* e = getenv("PSVAE_SCORER_ROWS"); return e && atoi(e) == 16 ? 16 : 32; }();
+    if (gine_layer_split(f.H)) {
+        a.PA = flb_pitch_bytes(P); a.PB = flb_pitch_bytes(P2);
+        const size_t planes2 = (size_t)3 * 32 * a.PB, off2 = (planes2 + 255) / 256 * 256;
+        const size_t lds = std::max((size_t)3 * 32 * a.PA, off2 + planes2);
+        static bool split_attr_set = false;
+        if (!split_attr_set) {
+            if (hipFuncSetAttribute((const void*)scorer_bwd_split_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
+                return (int)hipGetLastError();
+            split_attr_set = true;
+        }
+        if (lds > 159 * 1024) return PSVAE_E_SHAPE;
+        ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P));
+        hipLaunchKernelGGL((scorer_bwd_split_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a, (int)off2);
+        PSVAE_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)rows * (a.PA + a.PB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -472,6 +472,188 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient product (both operands arrive [reduction][output]) on the bf16 matrix instruction at fp32
+// accuracy.  Every fp32 element is cut EXACTLY into three bf16 pieces x = h + m + l (each the round-to-nearest bf16
+// of what the pieces before it leave: |m| <= 2^-9 |x|, |l| <= 2^-18 |x|) as it is written to LDS, and a product a.b
+// becomes the six piece products down to 2^-18 of it, hh + (hm + mh) + (mm + hl + lh); what is left out is below
+// 2^-26 |a||b|, a quarter of one fp32 rounding.  The piece products are exact in fp32; hh goes to the main
+// accumulator, the five small ones to a second one that joins it at the end (the instruction rounds its accumulator
+// at the accumulator's magnitude, so small terms must not be added to the large sum one by one).  Twelve
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) replace sixteen v_mfma_f32_32x32x2_f32 (64 cycles each) per K-step.
+// LDS image of an operand tile: three planes [32 reduction rows][64 outputs] of bf16, written as they arrive
+// (8 bytes per thread and plane) with a row pitch of 192 bytes; the matrix instruction wants 8 consecutive
+// reduction indices of one output per lane, i.e. columns of that image, which ds_read_b64_tr_b16 delivers (per 16
+// lanes a block of 4 rows x 16 outputs, transposed; the pitch puts the four rows of a 32-lane half on disjoint
+// banks).  Same tiles, grid, slab split and epilogue as gemm_f32_kernel<true, true, ..>.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+constexpr int SP_PITCH = 192, SP_PLANE = BK * SP_PITCH, SP_OPER = 3 * SP_PLANE, SP_BUF = 2 * SP_OPER;
+
+__device__ __forceinline__ unsigned bf_pair(float a, float b) {         // (a, b) -> two bf16, round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{a, b}, bf16x2));
+}
+// four consecutive outputs of one reduction row into the three planes
+__device__ __forceinline__ void cut_quad(char* plane0, int off, float4 v) {
+    const unsigned h0 = bf_pair(v.x, v.y), h1 = bf_pair(v.z, v.w);
+    const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xFFFF0000u);
+    const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = bf_pair(rx, ry), m1 = bf_pair(rz, rw);
+    const float sx = rx - __uint_as_float(m0 << 16), sy = ry - __uint_as_float(m0 & 0xFFFF0000u);
+    const float sz = rz - __uint_as_float(m1 << 16), sw = rw - __uint_as_float(m1 & 0xFFFF0000u);
+    const unsigned l0 = bf_pair(sx, sy), l1 = bf_pair(sz, sw);
+    *reinterpret_cast<uintx2*>(plane0 + off) = uintx2{h0, h1};
+    *reinterpret_cast<uintx2*>(plane0 + SP_PLANE + off) = uintx2{m0, m1};
+    *reinterpret_cast<uintx2*>(plane0 + 2 * SP_PLANE + off) = uintx2{l0, l1};
+}
+// (no branch: reduction rows past the range are zeroed by selects, so that the cut can be scheduled between the
+//  matrix instructions of the step before; outputs past the matrix keep whatever their clamped loads returned, they
+//  only meet outputs the epilogue never writes)
+__device__ __forceinline__ void cut_stage(char* oper, const Stage& st, const TileGeo& g, int r0, int tid) {
+    // quad q: reduction row q >> 4, outputs 4 (q & 15) .. + 3
+    const int off0 = (tid >> 4) * SP_PITCH + (tid & 15) * 8, off1 = off0 + 16 * SP_PITCH;
+    const bool ok0 = r0 + (tid >> 4) < g.r_lim, ok1 = r0 + 16 + (tid >> 4) < g.r_lim;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    cut_quad(oper, off0, ok0 ? patch_ones<true>(st.v0, g, tid) : zero);
+    cut_quad(oper, off1, ok1 ? patch_ones<true>(st.v1, g, tid + 256) : zero);
+}
+
+#define PSVAE_TR_READ(DST_, ADDR_, OFF_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_))
+
+__global__ __launch_bounds__(256) void gemm_dw_split_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char sp_lds[];      // [2 buffers][A, B][3 planes][32][192 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // (tile order: see gemm_f32_kernel)
+    const unsigned gxy = gridDim.x * gridDim.y, nb = gxy * gridDim.z;
+    const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = bid & 7u, per = nb >> 3, rem = nb & 7u;
+    const unsigned tile = xcd * per + min(xcd, rem) + (bid >> 3);
+    const int z = tile / gxy, txy = tile - z * gxy;
+    const int tx = txy / gridDim.y, ty = txy - tx * gridDim.y;
+    const int seg = z / p.splits, sp = z - seg * p.splits;
+    const float* A = p.A + seg * p.seg_a;
+    const float* B = p.B + seg * p.seg_b;
+    const int m0 = tx * BM, n0 = ty * BN;
+    const int rbeg = sp * p.rchunk;
+    const int rend = min(p.R, rbeg + p.rchunk);
+    const int nk = (rend - rbeg + BK - 1) / BK;
+
+    floatx16 acc, lo;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; lo[i] = 0.f; }
+
+    if (nk > 0) {
+        const TileGeo ga{A, p.lda, m0, p.M, rend, -1}, gb{B, p.ldb, n0, p.N, rend, p.ones_col};
+        // transposed-read addresses: lane 4 q + pp of a 16-lane group supplies row q, outputs 4 pp .. + 3 of the
+        // group's 4 x 16 block; group g = lane >> 4 takes outputs 16 (g & 1) .. + 15 of the wave's 32 and the
+        // reduction rows 8 (g >> 1) .. + 7 of a 16-row chunk (the instruction's lane map: row l & 31, k = 8 (l >> 5) + j)
+        const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        const unsigned lane_off = (unsigned)((8 * (grp >> 1) + q) * SP_PITCH + (16 * (grp & 1) + 4 * pp) * 2);
+        const unsigned a_rd = lane_off + wm * 64, b_rd = SP_OPER + lane_off + wn * 64;     // + buffer offset
+        const int rlast = rbeg + (nk - 1) * BK;
+        const unsigned lds0 = (unsigned)(size_t)sp_lds;       // (the low half of a shared-memory pointer is its LDS offset)
+        // Two register stages: while tile t is multiplied out of one LDS buffer, tile t+1 (loaded a step earlier) is
+        // cut into the other buffer BETWEEN the matrix instructions (they hold the vector issue port for a quarter
+        // of their time; the cut is ~150 vector instructions per step), and the loads of tile t+2 are in flight.
+        Stage sa0 = load_stage<true, true>(ga, rbeg, tid), sb0 = load_stage<true, true>(gb, rbeg, tid);
+        Stage sa1 = load_stage<true, true>(ga, min(rbeg + BK, rlast), tid), sb1 = load_stage<true, true>(gb, min(rbeg + BK, rlast), tid);
+        cut_stage(sp_lds, sa0, ga, rbeg, tid);
+        cut_stage(sp_lds + SP_OPER, sb0, gb, rbeg, tid);
+        __syncthreads();
+#define PSVAE_DW_STEP(T_, CUR_, NXT_, SA_CUT_, SB_CUT_, SA_LD_, SB_LD_)                                                  \
+        {                                                                                                                 \
+            SA_LD_ = load_stage<true, true>(ga, min(rbeg + ((T_) + 2) * BK, rlast), tid);   /* (past the end: unused) */  \
+            SB_LD_ = load_stage<true, true>(gb, min(rbeg + ((T_) + 2) * BK, rlast), tid);                                 \
+            const unsigned aa = lds0 + (CUR_) + a_rd, bb = lds0 + (CUR_) + b_rd;                                          \
+            uintx2 fa[2][3][2], fb[2][3][2];                                                                              \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                 \
+                _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                          \
+                    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                    \
+                        PSVAE_TR_READ(fa[c][pc][jj], aa, pc * SP_PLANE + (16 * c + 4 * jj) * SP_PITCH);                   \
+                        PSVAE_TR_READ(fb[c][pc][jj], bb, pc * SP_PLANE + (16 * c + 4 * jj) * SP_PITCH);                   \
+                    }                                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                               \
+                bf16x8 a3[3], b3[3];                                                                                      \
+                _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                        \
+                    a3[pc] = __builtin_bit_cast(bf16x8, uintx4{fa[c][pc][0].x, fa[c][pc][0].y, fa[c][pc][1].x, fa[c][pc][1].y}); \
+                    b3[pc] = __builtin_bit_cast(bf16x8, uintx4{fb[c][pc][0].x, fb[c][pc][0].y, fb[c][pc][1].x, fb[c][pc][1].y}); \
+                }                                                                                                         \
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], lo, 0, 0, 0);                                  \
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], lo, 0, 0, 0);                                  \
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], lo, 0, 0, 0);                                  \
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], lo, 0, 0, 0);                                  \
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], lo, 0, 0, 0);                                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc, 0, 0, 0);                                \
+            }                                                                                                             \
+            /* (on the last step this writes an all-zero tile nobody reads) */                                           \
+            cut_stage(sp_lds + (NXT_), SA_CUT_, ga, rbeg + ((T_) + 1) * BK, tid);                                         \
+            cut_stage(sp_lds + (NXT_) + SP_OPER, SB_CUT_, gb, rbeg + ((T_) + 1) * BK, tid);                               \
+            /* one matrix instruction, then a dozen of the cut's vector instructions and one of its LDS stores */        \
+            _Pragma("unroll") for (int u = 0; u < 12; ++u) {                                                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                                       \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                        \
+            }                                                                                                             \
+            __syncthreads();                                                                                              \
+        }
+        for (int t = 0; t < nk; t += 2) {
+            PSVAE_DW_STEP(t, 0, SP_BUF, sa1, sb1, sa0, sb0)
+            if (t + 1 >= nk) break;
+            PSVAE_DW_STEP(t + 1, SP_BUF, 0, sa0, sb0, sa1, sb1)
+        }
+#undef PSVAE_DW_STEP
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += lo[i];
+    }
+
+    // epilogue: as in gemm_f32_kernel (lane holds column j, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    const int j = n0 + wn * 32 + (lane & 31);
+    if (j >= p.N) return;
+    if (p.to_slab) {
+        float* C = p.C + (long long)z * p.slab_stride;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (i < p.M) C[(long long)i * p.N + j] = acc[reg];
+        }
+        return;
+    }
+    float* C = p.C + seg * p.seg_c;
+    const float bj = p.bias ? p.bias[seg * p.seg_bias + j] : 0.f;
+    const float* mask = p.mask ? p.mask + seg * p.seg_mask : nullptr;
+    const int row0 = m0 + wm * 32 + 4 * (lane >> 5);
+    float gate[16], old[16];
+    if (mask) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            gate[reg] = mask[(long long)min(row0 + (reg & 3) + 8 * (reg >> 2), p.M - 1) * p.ldmask + min(j, p.N - 1)];
+    }
+    if (p.accumulate && j != p.ones_col) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) old[reg] = C[(long long)min(row0 + (reg & 3) + 8 * (reg >> 2), p.M - 1) * p.ldc + j];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int i = row0 + (reg & 3) + 8 * (reg >> 2);
+        if (i >= p.M) continue;
+        float v = acc[reg] + bj;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (j == p.ones_col) {
+            if (p.c_extra) p.c_extra[i] = p.accumulate ? p.c_extra[i] + v : v;
+            continue;
+        }
+        if (mask && !(gate[reg] > 0.f)) v = 0.f;
+        C[(long long)i * p.ldc + j] = p.accumulate ? old[reg] + v : v;
+    }
+}
+#undef PSVAE_TR_READ
+
 // Sum `nz` slabs (fixed order z = 0..nz-1) and apply the epilogue.
 struct ReduceP {
     const float* slabs; long long slab_stride; int nz;
@@ -588,6 +770,23 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
         } while (0)
         // the interleaved loop pays where a CU holds few workgroups (split reductions are planned for at most 512)
         const bool pipe = (long long)grid.x * grid.y * grid.z <= 1024;
+        // Weight gradients of aligned operands: the cut-operand kernel on the bf16 matrix instruction.  Its K-step is
+        // bound by the vector instructions that cut the operands (every 64 x 32 tile is cut by each workgroup that uses
+        // it), not by the matrix pipe: per K-step it is on a par with the fp32 kernel (97 against 105 TFLOP/s at 95 k
+        // rows), but it needs 128 + 32 registers instead of 190 + 32 and shares a CU better with the other streams'
+        // kernels: +2 % on the 128-graph step, +1 % at 256 and 512 graphs, -1.5 % at 1024 (reductions over 19 k - 95 k rows
+        // there).  Used for reductions under 18 k rows;
+        // PSVAE_SPLIT_GEMM=0 / 1 forces fp32 / cut operands.
+        static const int split_forced = [] { const char* e = getenv("PSVAE_SPLIT_GEMM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+        if (d.a_t && d.b_t && vec && (split_forced >= 0 ? split_forced == 1 : d.R < 18432)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)gemm_dw_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SP_BUF) != hipSuccess)
+                    return (int)hipGetLastError();
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gemm_dw_split_kernel, grid, dim3(256), 2 * SP_BUF, s, p);
+        } else
         if (!d.a_t && !d.b_t) PSVAE_GEMM_LAUNCH(false, false);
         else if (!d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(false, true);
         else if (d.a_t && d.b_t) PSVAE_GEMM_LAUNCH(true, true);

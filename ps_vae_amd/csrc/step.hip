@@ -157,19 +157,26 @@ bool fused_layers_on() {
     static const bool on = [] { const char* e = getenv("PSVAE_FUSED_LAYER"); return !(e && e[0] == '0'); }();
     return on;
 }
-// The link scorer's forward pass as one launch (32 pairs per workgroup, one workgroup per CU) replaces the pair
-// gather, three GEMM launches and the head on the step's critical path: +1.4 % on the step while all its workgroups
-// fit the GPU in one round (128 graphs: 135 workgroups, and the CUs it leaves free go to the recurrence beside it),
-// -2.4 % / -1 % at 256 / 512 graphs (270 / 540 workgroups of ~100 us each: a second, nearly empty round), +-0 at 1024.
-// Default: forward fused up to 240 workgroups.  The fused backward was slower at every size and stays opt-in.
+// The link scorer as one launch per direction (32 pairs per workgroup, one workgroup per CU) instead of the pair
+// gather, three GEMM launches and the head.  Forward alone: pays while all its workgroups fit the GPU in one round
+// (128 graphs: 135 workgroups, and the CUs it leaves free go to the recurrence beside it; +1.4 % on the fp32
+// instruction), loses at 256 - 384 graphs (a second, nearly empty round).  Forward and backward together, on the
+// bf16 instruction over cut operands (gine_layer_split): -1.4 % at 384 graphs, +2.5 % at 512, +4.9 % at 768, +6.1 %
+// at 1024; at 128 graphs the one-launch backward still loses 1.2 % (its one-per-CU workgroups keep the recurrence's
+// backward, which needs its workgroups resident together, waiting for CUs).  Default: forward fused up to 240
+// workgroups; both from 480 workgroups up when the cut-operand kernels are on.
 // PSVAE_FUSED_SCORER: 0 = never, 1 = forward and backward always, 2 = forward always.
 int fused_scorer_mode() {
     static const int mode = [] { const char* e = getenv("PSVAE_FUSED_SCORER"); return e ? atoi(e) : -1; }();
     return fused_layers_on() ? mode : 0;
 }
-bool fused_scorer_fwd_on(int S) {
+bool fused_scorer_fwd_on(int S, int H) {
+    const int m = fused_scorer_mode(), wgs = (S + 31) / 32;
+    return m == 1 || m == 2 || (m < 0 && S > 0 && (wgs <= 240 || (gine_layer_split(H) && wgs >= 480)));
+}
+bool fused_scorer_bwd_on(int S, int H) {
     const int m = fused_scorer_mode();
-    return m == 1 || m == 2 || (m < 0 && S > 0 && (S + 31) / 32 <= 240);
+    return m == 1 || (m < 0 && gine_layer_split(H) && (S + 31) / 32 >= 480);
 }
 // The fused backward of the GINE MLPs.  On the fp32 matrix instruction it pays once a launch holds more row tiles
 // than the GPU has compute units (measured: -1.2 % at 128 graphs per step, +0.6 % at 256, +2.2 % at 512); on the
@@ -469,7 +476,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     // stacks, link scorer): off the dependent chain, which needs them only after the embeddings and node_trans
     const bool dec_only = b.conds != nullptr;
     const bool fused_gine = fused_layers_on() && gine_layer_fused_supported(s.H, s.H, s.H);
-    const bool fused_scorer = fused_scorer_fwd_on(s.S) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    const bool fused_scorer = fused_scorer_fwd_on(s.S, s.H) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     hipEvent_t packed = nullptr;
     if (L && (fused_gine || fused_scorer)) {
         PSVAE_TRY(hand_over(st, s2, L->ev[5]));
@@ -569,7 +576,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
         }
         PSVAE_TRY(fused_pack(s2, pk, cnt));
     }
-    const bool fused_scorer = fused_scorer_mode() == 1 && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    const bool fused_scorer = fused_scorer_bwd_on(s.S, s.H) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     float* spack_bwd = w.spack + scorer_pack_floats(s.H, s.Z);
     if (fused_scorer) PSVAE_TRY(scorer_pack_bwd(s2, p.sc_w0, p.sc_w1, p.sc_w2, spack_bwd, s.H, s.Z));
     if (L && (fused_gine || fused_scorer) && hipEventRecord(L->ev[15], s2) != hipSuccess) return (int)hipGetLastError();
