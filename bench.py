@@ -34,8 +34,11 @@ from ps_vae_amd.parallel import GradReducer, OverlappedReducer, shard_range  # n
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+# dense bf16 matrix peak / 6: the rate at which the cut-operand kernels (fp32 operands as three bf16 pieces, six
+# v_mfma_*_bf16 per fp32-accurate product block) could deliver fp32-equivalent flops
+MFMA_CUT_PEAK_TF = 2500.0 / 6
 FLOP_CLASSES = ('gemm_forward', 'gemm_input_grad', 'gemm_weight_grad', 'gru_forward', 'gru_backward', 'gine_layer_fused',
-                'scorer_fused')
+                'scorer_fused', 'gine_layer_fused_bwd')
 
 
 def make_batches(tok, vocab, shape, batch_size, count, seed, host_times=None):
@@ -516,7 +519,11 @@ def main():
                    'grad_reduce': (type(leg.reducer).__name__ + f', denominators: {leg.denoms_mode}') if dist_on else None,
                    'final_loss': res['final_loss'], 'host_collate_ms_per_batch': leg.collate_s * 1e3,
                    'device_collate_ms_per_batch': dev_collate_ms,
-                   'host_enqueue_ms_per_step': res['host_enqueue_ms_per_step']},
+                   'host_enqueue_ms_per_step': res['host_enqueue_ms_per_step'],
+                   'arithmetic': 'fp32 values and fp32 accumulation everywhere; the fused GINE and link-scorer kernels and the '
+                                 'weight-gradient products over fewer than 18 k rows form each fp32 product from exact three-way '
+                                 'bf16 cuts of both operands (six v_mfma_*_bf16 per block), error against float64 at or below '
+                                 'that of plain fp32 arithmetic (tests/test_gpu_ops.py); the other products run on v_mfma_f32_*'},
         'roofline': roofline,
         'message_passing': {'kernels': mp, 'bound': 'hbm', 'achieved': (mp_bytes / (mp_ms * 1e-3) / 1e9) if mp_ms else None,
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -537,7 +544,10 @@ def main():
             hbm = agg_bytes / (fms / fcnt * 1e-3) / 1e9
             mf = fwork / (fms * 1e-3) / 1e12
             out['fused_layer'] = {'kernel': 'gine_layer_fused', 'avg_launch_us': fms / fcnt * 1e3,
-                                  'mfma': {'achieved': mf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mf / MFMA_F32_PEAK_TF},
+                                  'mfma': {'achieved': mf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mf / MFMA_F32_PEAK_TF,
+                                           'instruction': 'v_mfma_f32_16x16x32_bf16, six per fp32 product block (operands cut into '
+                                                          'three bf16 pieces; fp32-accurate, see tests/test_gpu_ops.py)',
+                                           'peak_cut_operands': MFMA_CUT_PEAK_TF, 'frac_cut_operands': mf / MFMA_CUT_PEAK_TF},
                                   'hbm': {'achieved': hbm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm / HBM_PEAK_GBS,
                                           'algorithmic_bytes_per_launch': agg_bytes},
                                   'frac': max(mf / MFMA_F32_PEAK_TF, hbm / HBM_PEAK_GBS)}

@@ -1497,7 +1497,7 @@ int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, 
     const size_t lds = split ? (size_t)3 * rows * a.P : (size_t)FL_ROWS * a.P * sizeof(float);
     const int CT = fused_ct(H);
     const dim3 grid((n + rows - 1) / rows, ng);
-    ProfScope prof(s, KC_GINE_LAYER, 4.0 * n * H * H * ng);
+    ProfScope prof(s, KC_GINE_LAYER_BWD, 4.0 * n * H * H * ng);
 #define FLBS_LAUNCH2(CT_, RT_)                                                                                        \
     do {                                                                                                              \
         if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_bwd_split_kernel<CT_, RT_>,                \

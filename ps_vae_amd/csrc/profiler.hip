@@ -43,7 +43,7 @@ extern "C" const char* psvae_profile_class_name(int kc) {
     static const char* names[KC_COUNT] = {
         "gemm_forward", "gemm_input_grad", "gemm_weight_grad", "gemm_slab_reduce", "gine_aggregate_fwd",
         "gine_aggregate_bwd", "gine_edge_grad", "embed_gather", "table_grad", "segment_pool", "pair_gather",
-        "pair_scatter", "gru_forward", "gru_backward", "softmax_ce", "head_misc", "clip_adam", "gine_layer_fused", "scorer_fused"};
+        "pair_scatter", "gru_forward", "gru_backward", "softmax_ce", "head_misc", "clip_adam", "gine_layer_fused", "scorer_fused", "gine_layer_fused_bwd"};
     return (kc >= 0 && kc < KC_COUNT) ? names[kc] : "?";
 }
 

@@ -22,7 +22,7 @@ static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * 
 // ---------------------------------------------------------------- launch timer (profiler.hip)
 enum KernelClass {
     KC_GEMM_FWD = 0, KC_GEMM_DX, KC_GEMM_DW, KC_GEMM_REDUCE, KC_AGG_FWD, KC_AGG_BWD, KC_ETAB, KC_EMBED, KC_TABLE_GRAD,
-    KC_POOL, KC_PAIR_GATHER, KC_PAIR_SCATTER, KC_GRU_FWD, KC_GRU_BWD, KC_CE, KC_HEAD, KC_ADAM, KC_GINE_LAYER, KC_SCORER, KC_COUNT
+    KC_POOL, KC_PAIR_GATHER, KC_PAIR_SCATTER, KC_GRU_FWD, KC_GRU_BWD, KC_CE, KC_HEAD, KC_ADAM, KC_GINE_LAYER, KC_SCORER, KC_GINE_LAYER_BWD, KC_COUNT
 };
 struct ProfScope {
     ProfScope(hipStream_t s, int kc, double work);

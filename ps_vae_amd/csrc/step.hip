@@ -695,6 +695,21 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     // weight gradients of the shared GINE MLPs (sum over the t applications): encoder on lane 1,
     // decoder-side encoder on lane 2, beside node_trans / edge_trans / embedding tables on main
     if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[8])); PSVAE_TRY(hand_over(st, s2, L->ev[9])); }
+    // (the edge-table sums - two short launches of a few workgroups - go to lane 2 in front of its products while the
+    //  batch is small: the caller's stream, which still has node_trans and the embedding tables to do, is then the
+    //  last of the three to finish, +1.3 % at 128 graphs per step; at 1024 graphs the second of the two launches waits
+    //  behind the long-running weight-gradient workgroups wherever it is queued, and in front of lane 2's products
+    //  it delays them: -0.6 %.  PSVAE_ETAB_LANE=0 / 1 forces the caller's stream / lane 2.)
+    static const int etab_forced = [] { const char* e = getenv("PSVAE_ETAB_LANE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    hipStream_t se = (etab_forced >= 0 ? etab_forced == 1 : s.n <= 12288) ? s2 : st;
+    if (dec_only) {
+        PSVAE_TRY(stacks_edge_grads(se, s, w, &k[1], 1, 1));
+    } else if (s.te == s.td) {
+        PSVAE_TRY(stacks_edge_grads(se, s, w, k, 2, 0));
+    } else {
+        PSVAE_TRY(stacks_edge_grads(se, s, w, &k[0], 1, 0));
+        PSVAE_TRY(stacks_edge_grads(se, s, w, &k[1], 1, 1));
+    }
     for (int q = dec_only ? 1 : 0; q < 2; ++q) {
         hipStream_t sq = q == 0 ? s1 : s2;
         float* scq = q == 0 ? sc1 : sc2;
@@ -702,14 +717,6 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
                                s.n, s.H, s.H, scq, scf));
         PSVAE_TRY(linear_bwd_w(sq, k[q].DH, s.H, (int64_t)nH, k[q].A, s.H, (int64_t)nH, k[q].t, k[q].g_w1, k[q].g_b1,
                                s.n, s.H, s.H, scq, scf));
-    }
-    if (dec_only) {
-        PSVAE_TRY(stacks_edge_grads(st, s, w, &k[1], 1, 1));
-    } else if (s.te == s.td) {
-        PSVAE_TRY(stacks_edge_grads(st, s, w, k, 2, 0));
-    } else {
-        PSVAE_TRY(stacks_edge_grads(st, s, w, &k[0], 1, 0));
-        PSVAE_TRY(stacks_edge_grads(st, s, w, &k[1], 1, 1));
     }
     // --- node_trans of both stacks from G0 = [dL/dx0_enc | dL/dx0_dec]  ([n, 2H])
     const bool node_adjacent = p.dec_node_w == p.enc_node_w + (size_t)s.H * s.Din && g.dec_node_w == g.enc_node_w + (size_t)s.H * s.Din &&

@@ -13,14 +13,14 @@ import sys
 
 CLASSES = [  # (substring of the kernel name, kernel class as bench.py reports it)
     ('gemm_f32_kernel<false, false', 'gemm_forward'), ('gemm_f32_kernel<false, true', 'gemm_input_grad'),
-    ('gemm_f32_kernel<true,', 'gemm_weight_grad'), ('gemm_reduce_kernel', 'gemm_slab_reduce'),
+    ('gemm_f32_kernel<true,', 'gemm_weight_grad'), ('gemm_dw_split_kernel', 'gemm_weight_grad'), ('gemm_reduce_kernel', 'gemm_slab_reduce'),
     ('gine_agg_fwd_kernel', 'gine_aggregate_fwd'), ('gine_agg_bwd_kernel', 'gine_aggregate_bwd'),
     ('gine_etab_reduce_kernel', 'gine_edge_grad'), ('embed3_gather_kernel', 'embed_gather'), ('rows_gather_kernel', 'embed_gather'),
     ('table_grad_', 'table_grad'), ('segment_pool_kernel', 'segment_pool'), ('pair_gather_kernel', 'pair_gather'),
     ('pair_scatter_kernel', 'pair_scatter'), ('gru_fwd', 'gru_forward'), ('gru_bwd', 'gru_backward'),
     ('softmax_ce_', 'softmax_ce'), ('sqnorm_partial_kernel', 'clip_adam'), ('clip_adam_kernel', 'clip_adam'),
-    ('gine_layer_fwd_kernel', 'gine_layer_fused'), ('gine_layer_bwd_kernel', 'gine_layer_fused'),
-    ('scorer_fwd_kernel', 'scorer_fused'), ('scorer_bwd_kernel', 'scorer_fused'), ('pack_weights_kernel', 'weight_pack'),
+    ('gine_layer_fwd_', 'gine_layer_fused'), ('gine_layer_bwd_', 'gine_layer_fused_bwd'),
+    ('scorer_fwd_', 'scorer_fused'), ('scorer_bwd_', 'scorer_fused'), ('pack_weights_', 'weight_pack'),
     ('normal_rows_kernel', 'epsilon_draw'),
 ]
 
