@@ -689,18 +689,18 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
     }
 }
 
-// Reduction split: a launch of few tiles is split along the reduction range into at most 384 workgroups - one to
-// two per CU, all resident at once, each with at least 4 K-steps; these launches run beside other streams' work in
-// the training step, where 512 cost the step 1.3 %, 256 0.6 % and rounding the slab count up instead of down
-// 1 %.  Reductions over 32 k rows or more (bulk weight gradients, a launch that has the GPU to itself for
-// hundreds of microseconds) get 512: 88 instead of 72 TFLOP/s at 95 k rows.  PSVAE_SPLIT_TARGET overrides both.
+// Reduction split: a launch of few tiles is split along the reduction range into at most 512 workgroups - two per
+// CU, all resident at once, each with at least 4 K-steps; these launches run beside other streams' work in the
+// training step.  (While the weight gradients ran on the fp32 kernel - 190 registers, one to two workgroups per CU -
+// 384 was the better target there: 512 cost the step 1.3 %; with the cut-operand kernel, which shares a CU better,
+// 512 gains 0.7 %, 256 and 768 lose as much.)  PSVAE_SPLIT_TARGET overrides.
 struct Plan { int splits, rchunk; };
 Plan plan_splits(int M, int N, int R, int nseg) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nseg;
     Plan pl{1, (int)round_up(R > 0 ? R : 1, BK)};
     if (tiles >= 200 || R <= 4 * BK) return pl;
     static const int forced = [] { const char* e = getenv("PSVAE_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
-    const int target = forced > 0 ? forced : (R >= 32768 ? 512 : 384);
+    const int target = forced > 0 ? forced : 512;
     int want = (int)(target / tiles);      // rounded down
     int maxs = R / (4 * BK);
     if (want > maxs) want = maxs;
