@@ -289,7 +289,11 @@ int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr,
  * there for the second product: neither is read back from memory.  agg and hid ([n,H] each, both or neither)
  * receive copies for a backward pass; NULL = inference.  H a multiple of 4, 16 <= H <= 512, ldx % 4 == 0.
  * `scratch` (psvae_gine_layer_scratch_bytes(H) bytes, 16-byte aligned) receives the two weight matrices re-laid
- * for the matrix cores' operand fragments (the whole-step entry points do that once per step). */
+ * for the matrix cores' operand fragments (the whole-step entry points do that once per step).
+ * Arithmetic: fp32 in, fp32 out, fp32 accumulation.  The two products run on the bf16 matrix instruction over
+ * operands cut exactly into three bf16 pieces each (x = h + m + l), six piece products per product; the result is
+ * at least as close to the exact one as a chain of fp32 multiply-adds (the environment switch PSVAE_SPLIT_BF16=0
+ * selects the fp32 matrix instruction instead). */
 size_t psvae_gine_layer_scratch_bytes(int H);
 int psvae_gine_layer_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
                              const float* edge_w, const float* edge_b, float one_plus_eps, const float* w1,
@@ -325,7 +329,9 @@ int psvae_segment_pool_forward(const float* x, int ldx, const int32_t* graph_off
 /* nn.GRU(batch_first, 1 layer) over T steps given gi = x W_ih^T + b_ih. src/modules/vae_piece_decoder.py:29,89
  * `exchange`: device scratch of psvae_gru_exchange_bytes(B,T,R) bytes, 16-byte aligned, through which the
  * workgroups that share a sequence tile hand each other the hidden state every step (multi-CU recurrence,
- * 16 <= R <= 256).  NULL selects the single-CU kernels (one workgroup per 16 sequences).  Two calls that use
+ * 16 <= R <= 256).  NULL selects the single-CU kernels (one workgroup per 16 sequences), which the library also takes
+ * by itself for more than 768 sequences, where the multi-CU kernels' waiting workgroups cost the kernels of other
+ * streams more than the shorter recurrence gains (then the buffer is left untouched).  Two calls that use
  * the same exchange buffer must not overlap. */
 size_t psvae_gru_exchange_bytes(int B, int T, int R);
 int psvae_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
