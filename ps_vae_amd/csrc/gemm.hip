@@ -771,9 +771,10 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
         // the interleaved loop pays where a CU holds few workgroups (split reductions are planned for at most 512)
         const bool pipe = (long long)grid.x * grid.y * grid.z <= 1024;
         // Weight gradients of aligned operands: the cut-operand kernel on the bf16 matrix instruction.  Its K-step is
-        // bound by the vector instructions that cut the operands (every 64 x 32 tile is cut by each workgroup that uses
-        // it), not by the matrix pipe: per K-step it is on a par with the fp32 kernel (97 against 105 TFLOP/s at 95 k
-        // rows), but it needs 128 + 32 registers instead of 190 + 32 and shares a CU better with the other streams'
+        // bound by LDS traffic (48 KB of transposed fragment reads per step: three planes per operand, each tile read
+        // by two waves), not by the matrix pipe and not by the cut (staging operands that arrive already cut changed
+        // nothing): per K-step it is on a par with the fp32 kernel (97 against 105 TFLOP/s at 95 k rows), but it needs
+        // 128 + 32 registers instead of 190 + 32 and shares a CU better with the other streams'
         // kernels: +2 % on the 128-graph step, +1 % at 256 and 512 graphs, -1.5 % at 1024 (reductions over 19 k - 95 k rows
         // there).  Used for reductions under 18 k rows;
         // PSVAE_SPLIT_GEMM=0 / 1 forces fp32 / cut operands.
