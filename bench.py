@@ -296,6 +296,9 @@ class Leg:
                 self.reducer.reduce_denoms(nb.local_denoms, out=nb.denoms)
             torch.cuda.synchronize()
         self.unit = model.unit_grad()       # loss.backward(unit): no fill / copy launches for the implicit gradient of 1
+        # PSVAE_BENCH_AUTOGRAD=1: the step through torch.autograd (training_step, backward, optimizer.step) instead of
+        # PSVAEModel.train_step - same kernels, more host time
+        self.one_call = os.environ.get('PSVAE_BENCH_AUTOGRAD') != '1'
 
     def step(self, i):
         model, n = self.model, self.n_distinct
@@ -304,8 +307,12 @@ class Leg:
         if self.denoms_mode == 'ride' and not self.delivered.pop(i, False):     # first step only: nothing has carried them yet
             self.reducer.reduce_denoms(nb.local_denoms, out=nb.denoms)
         self.opt.zero_grad()
-        loss = model.training_step(batch)       # epsilon: counter-based draw keyed by (seed, step, global graph index)
-        loss.backward(self.unit)
+        # epsilon: counter-based draw keyed by (seed, step, global graph index)
+        if self.one_call:       # forward, backward (and, alone on the GPU, clip + Adam) queued by one library call
+            loss = model.train_step(batch, None if self.dist_on else self.opt)[5]
+        else:
+            loss = model.training_step(batch)
+            loss.backward(self.unit)
         if self.dist_on:
             if self.shared_gpu:
                 torch.cuda.synchronize()
@@ -321,7 +328,8 @@ class Leg:
                 self.delivered[i + 1] = True
             if self.shared_gpu:
                 torch.cuda.synchronize()
-        self.opt.step()
+        if self.dist_on or not self.one_call:
+            self.opt.step()
         model.global_step += 1
         return loss
 
@@ -341,7 +349,8 @@ class Leg:
         marks[0].record()
         for i in range(steps):
             loss = self.step(warmup + i)
-            marks[i + 1].record()       # per-step spread (median, p10, p90); the headline stays total time / steps
+            if not os.environ.get('PSVAE_BENCH_NO_MARKS') or i == steps - 1:
+                marks[i + 1].record()       # per-step spread (median, p10, p90); the headline stays total time / steps
         host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
         self.fence()
         elapsed = time.perf_counter() - t0
@@ -352,7 +361,7 @@ class Leg:
             elapsed = float(t)
             # a rank's loss is its share of the global batch's loss (local sums over global counts)
             torch.distributed.all_reduce(final, op=torch.distributed.ReduceOp.SUM)
-        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)) if not os.environ.get('PSVAE_BENCH_NO_MARKS') else [elapsed / steps * 1e3] * steps
         spread = {'median': per_step[len(per_step) // 2], 'p10': per_step[int(0.1 * (len(per_step) - 1))],
                   'p90': per_step[int(0.9 * (len(per_step) - 1))]}
         if self.model.recurrence_gave_up():

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 3
+#define PSVAE_ABI_VERSION 4
 
 enum {
     PSVAE_OK = 0,
@@ -176,6 +176,24 @@ int psvae_step_backward_signal(const psvae_dims* dims, const psvae_params* param
                                void* workspace, size_t workspace_bytes, const float* loss_weights,
                                const float* loss_grads, const psvae_params* grads, void* stream,
                                void* early_event_1, void* early_event_2);
+/* One optimiser step in ONE call: psvae_step_forward, psvae_step_backward_signal with `loss_grads` (normally the
+ * constant [0,0,0,0,0,1]: the gradient of the weighted total) and, when `opt` is given, psvae_clip_adam over the flat
+ * buffers it names.  This is the body of Lightning's training loop for this model (src/pl_models/ps_vae_model.py:76-88
+ * `training_step` -> loss.backward() -> src/train.py:47 gradient clipping -> ps_vae_model.py:123-127 Adam) with no
+ * host code between the three parts; the enqueued work, and so every result, is that of the three calls.  A
+ * data-parallel caller passes opt = NULL, reduces the gradients and calls psvae_clip_adam itself.  `grads` must
+ * describe the same memory as opt->grads (tensor by tensor). */
+typedef struct psvae_adam {
+    float *params, *grads, *exp_avg, *exp_avg_sq;    /* flat fp32 buffers of `count` elements */
+    int64_t count;
+    float* partials;                                  /* psvae_adam_partials(count) floats */
+    float max_norm, lr, beta1, beta2, eps, bias1, bias2;
+    float* grad_norm_out;                             /* device, may be NULL */
+} psvae_adam;
+int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
+                     size_t workspace_bytes, const float* loss_weights, float* losses, const float* loss_grads,
+                     const psvae_params* grads, const psvae_adam* opt, void* early_event_1, void* early_event_2,
+                     void* stream);
 /* Creates the current device's two internal side streams now rather than inside the first step call, and checks
  * (with two 100 us probe kernels per pair, timed from the host) that they and `stream` -- the stream the step
  * calls will be given, NULL for the default stream -- run side by side; a side stream that does not is replaced

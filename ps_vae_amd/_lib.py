@@ -72,6 +72,11 @@ BATCH_PTRS = (
 BLOB_FIELDS = BATCH_PTRS
 
 
+class Adam(C.Structure):
+    _fields_ = ([(k, vp) for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq')] + [('count', i64), ('partials', vp)] +
+                [(k, f32) for k in ('max_norm', 'lr', 'beta1', 'beta2', 'eps', 'bias1', 'bias2')] + [('grad_norm_out', vp)])
+
+
 class Batch(C.Structure):
     _fields_ = ([(k, i32) for k in ('B', 'n', 'E', 'E_in', 'S', 'L')] + [(k, vp) for k in BATCH_PTRS] +
                 [('props', vp), ('eps', vp), ('denoms', vp), ('conds', vp), ('d_conds', vp), ('d_z', vp), ('status', vp)])
@@ -108,6 +113,7 @@ def lib():
     L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp]
     L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp]
     L.psvae_step_backward_signal.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp, vp, vp]
+    L.psvae_train_step.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp, P(Params), P(Adam), vp, vp, vp]
     L.psvae_streams_init.argtypes = [vp]
     L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
     L.psvae_sample_pieces_workspace_bytes.restype = sz
@@ -165,14 +171,14 @@ def lib():
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
     L.psvae_profile_event_overhead_ms.restype = C.c_double
     L.psvae_profile_event_overhead_ms.argtypes = [vp]
-    if L.psvae_abi_version() != 3:
+    if L.psvae_abi_version() != 4:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
     return L
 
 
 EXPORTS = (
-    'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward',
+    'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward', 'psvae_train_step',
     'psvae_step_backward', 'psvae_step_backward_signal', 'psvae_streams_init', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
     'psvae_score_links', 'psvae_normal_rows', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',

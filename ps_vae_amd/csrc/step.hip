@@ -759,6 +759,21 @@ extern "C" int psvae_step_backward_signal(const psvae_dims* dims, const psvae_pa
                          (hipEvent_t)early_event_1, (hipEvent_t)early_event_2);
 }
 
+extern "C" int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
+                                size_t workspace_bytes, const float* loss_weights, float* losses, const float* loss_grads,
+                                const psvae_params* grads, const psvae_adam* opt, void* early_event_1, void* early_event_2,
+                                void* stream) {
+    PSVAE_TRY(psvae_step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream));
+    PSVAE_TRY(step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
+                            (hipEvent_t)early_event_1, (hipEvent_t)early_event_2));
+    if (opt) {
+        if (!opt->params || !opt->grads || !opt->exp_avg || !opt->exp_avg_sq || !opt->partials) return PSVAE_E_NULL;
+        PSVAE_TRY(psvae_clip_adam(opt->params, opt->grads, opt->exp_avg, opt->exp_avg_sq, opt->count, opt->partials, opt->max_norm,
+                                  opt->lr, opt->beta1, opt->beta2, opt->eps, opt->bias1, opt->bias2, opt->grad_norm_out, stream));
+    }
+    return 0;
+}
+
 extern "C" int psvae_encode(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
                             void* workspace, size_t workspace_bytes, float* z_mean, float* z_log_var, void* stream) {
     PSVAE_TRY(check_dims(dims, batch));

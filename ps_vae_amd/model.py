@@ -131,6 +131,7 @@ class PSVAEModel(nn.Module):
         self._unit = None
         self._early_events = None
         self._status = None
+        self._ws_bytes, self._ws_keep = {}, None
         self.last_backward_signalled = False
         # epsilon of rsample: counter-based, keyed by (eps_seed, number of forward passes so far, global graph index)
         self.eps_seed = int(config.get('seed', 2021)) if hasattr(config, 'get') else 2021
@@ -380,6 +381,53 @@ class PSVAEModel(nn.Module):
         fused step (same value as `weighted_loss(pred, rec, kl)` at the current `global_step`)."""
         self.forward(batch, eps=eps)
         return self._last_total
+
+    def train_step(self, batch, optimizer=None, eps=None):
+        """One optimiser step as ONE library call (`psvae_train_step`): `training_step`, `loss.backward()`, gradient
+        clipping and `optimizer.step()` of the reference's loop (`ps_vae_model.py:76-88`, `src/train.py:47`,
+        `ps_vae_model.py:123-127`) with no Python or autograd between them - the same kernels in the same order, so the
+        same numbers, at two thirds of the host time.  Returns the six losses `[pred, rec, piece, edge, kl, total]` (a
+        device tensor, no synchronisation).  Without `optimizer` only forward and backward run and the gradients are
+        left in the flat buffer (`flat_buffers()`, the parameters' `.grad`): the data-parallel form - reduce them, then
+        `optimizer.step()`.  Needs the gradient buffer empty (`zero_grad()`, which `optimizer.step()` implies)."""
+        self._sync_flat()
+        if not self._flat.is_cuda:
+            raise RuntimeError('PSVAEModel runs on the GPU only: move it with .cuda() (no CPU implementation exists)')
+        if not self._grads_fresh:
+            raise RuntimeError('train_step writes the gradients of one step: call zero_grad() (or optimizer.step()) first; '
+                               'use training_step + backward to accumulate gradients over several batches')
+        nb = self._native(batch)
+        dev = self._flat.device
+        if eps is None:
+            eps = self.draw_eps(nb.sizes['B'], self._first_graph(nb))
+        eps = eps.to(dev, torch.float32).contiguous()
+        L = _lib.lib()
+        bs = nb.struct(eps, self._status_words(dev))
+        key = tuple(nb.sizes[k] for k in ('B', 'n', 'E', 'E_in', 'S', 'L'))
+        nbytes = self._ws_bytes.get(key)
+        if nbytes is None:
+            nbytes = self._ws_bytes[key] = L.psvae_workspace_bytes(C.byref(self._dims), C.byref(bs))
+            if nbytes == 0:
+                raise RuntimeError('psvae_workspace_bytes rejected the model/batch sizes')
+        if self._ws_keep is None or self._ws_keep.numel() < nbytes or self._ws_keep.device != dev:
+            self._ws_keep = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # kept: every step reuses it
+        ws = self._ws_keep
+        losses = torch.empty(6, dtype=torch.float32, device=dev)
+        alpha = float(self.config['alpha'])
+        w3 = (C.c_float * 3)(1.0 - alpha, alpha, float(self.cal_beta()))
+        self.unit_grad()
+        ev = self._early_events
+        adam = optimizer.fused_struct() if optimizer is not None else None
+        _lib.check(L.psvae_train_step(C.byref(self._dims), C.byref(self._params_struct), C.byref(bs), ws.data_ptr(), nbytes,
+                                      C.byref(w3), losses.data_ptr(), self._unit[1].data_ptr(), C.byref(self._grads_struct),
+                                      C.byref(adam) if adam is not None else None,
+                                      ev[0].cuda_event if ev else None, ev[1].cuda_event if ev else None,
+                                      torch.cuda.current_stream(dev).cuda_stream), 'psvae_train_step')
+        self._last_ws = (ws, nb)
+        self._last_total = losses[5]
+        self.last_backward_signalled = ev is not None
+        self._grads_fresh = optimizer is not None      # (the optimiser consumed them: the next step overwrites)
+        return losses
 
     def validation_step(self, batch, batch_idx=0, eps=None):
         """`ps_vae_model.py:90-96`: weighted loss and the two accuracies of one batch."""

@@ -49,6 +49,23 @@ class FusedClipAdam:
                                      torch.cuda.current_stream().cuda_stream), 'psvae_clip_adam')
         self.model.zero_grad()
 
+    def fused_struct(self):
+        """The `psvae_adam` block of the NEXT step (advances the step count): what `PSVAEModel.train_step` hands to
+        `psvae_train_step` so that clip + Adam are queued by the same library call as forward and backward."""
+        params, grads = self.model.flat_buffers()
+        if not params.is_cuda:
+            raise RuntimeError('FusedClipAdam runs on the GPU only')
+        self._state(params)
+        self.step_count += 1
+        b1, b2 = self.betas
+        a = _lib.Adam()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = params.data_ptr(), grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.count, a.partials = params.numel(), self.partials.data_ptr()
+        a.max_norm, a.lr, a.beta1, a.beta2, a.eps = self.max_norm, self.lr, b1, b2, self.eps
+        a.bias1, a.bias2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        a.grad_norm_out = self.grad_norm.data_ptr()
+        return a
+
     def state_dict(self):
         return {'step': self.step_count, 'epoch': self.epoch, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
 

@@ -137,14 +137,14 @@ def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3
                 if nb.graph_base is None:       # shard position inside the global batch, for the epsilon draw
                     nb.graph_base = rank * nb.sizes['B']
             opt.zero_grad()
-            loss = model.training_step(batch)
-            loss.backward(model.unit_grad())
+            # training_step, backward (and, alone, clip + Adam) as one library call: same kernels, less host time
+            model.train_step(batch, None if dp else opt)
             if dp:
                 if hasattr(reducer, 'reduce'):
                     reducer.reduce()
                 else:
                     reducer.reduce_grads(model.flat_buffers()[1])
-            opt.step()
+                opt.step()
             model.global_step += 1
         # the multi-CU recurrence bounds its waits; a step in which a workgroup gave up holds garbage, and the
         # parameters must not be validated or saved (checked here, where the host synchronises anyway)

@@ -202,6 +202,49 @@ def test_gradient_accumulation_and_determinism():
     check_close(model.flat_buffers()[1], 2 * g1, 'accumulated gradient', rtol=1e-6)
 
 
+def test_train_step_entry_equals_the_three_calls():
+    """`PSVAEModel.train_step` (one `psvae_train_step` call: forward, backward, clip + Adam) against `training_step`,
+    `backward`, `optimizer.step()` through autograd: losses and parameters bit for bit over three steps; without an
+    optimiser it leaves the gradients of that step and refuses to run on top of gradients that are still there."""
+    from ps_vae_amd import synth
+    d, V, B = O.default_dims(300), 300, 24
+    mols = [synth.make_molecules(300 + i, 'zinc', V, B) for i in range(3)]
+    eps = [torch.randn(B, d['latent'], generator=torch.Generator().manual_seed(20 + i)) for i in range(3)]
+    runs = []
+    for one_call in (False, True):
+        model, tok, sd = build(d, V)
+        opt = model.configure_optimizers()
+        losses = []
+        for i in range(3):
+            _, batch = collate_both(mols[i], tok, V, 50 + i)
+            if one_call:
+                six = model.train_step(batch, opt, eps=eps[i])
+                losses.append(six.clone())
+            else:
+                opt.zero_grad()
+                pred, (rec, piece, edge, kl) = model(batch, eps=eps[i])
+                total = model._last_total
+                total.backward()
+                opt.step()
+                losses.append(torch.stack([pred, rec, piece, edge, kl, total]).detach().clone())
+            model.global_step += 1
+        runs.append((torch.stack(losses), model.flat_buffers()[0].clone(), opt.grad_norm.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]), 'losses'
+    assert torch.equal(runs[0][1], runs[1][1]), 'parameters after three steps'
+    assert torch.equal(runs[0][2], runs[1][2]), 'gradient norm of the last step'
+    # forward + backward only: the gradients equal those of the autograd path, and a second call must not overwrite them
+    model, tok, sd = build(d, V)
+    _, batch = collate_both(mols[0], tok, V, 50)
+    model.zero_grad()
+    model.training_step(batch, eps=eps[0]).backward()
+    want = model.flat_buffers()[1].clone()
+    model.zero_grad()
+    model.train_step(batch, None, eps=eps[0])
+    assert torch.equal(model.flat_buffers()[1], want)
+    with pytest.raises(RuntimeError):
+        model.train_step(batch, None, eps=eps[0])
+
+
 def test_module_level_encoder_matches_oracle():
     """Encoder.embed_node / embed_graph and Predictor through the single-operator API."""
     from ps_vae_amd import synth
