@@ -21,7 +21,7 @@
  *    same device concurrently would record and wait on the same events and share
  *    the same side streams, i.e. build wrong dependencies; serialise such callers
  *    (the other entry points have no such state).  Besides that the library holds,
- *    per device, one 16 MiB device array (psvae_linear_backward_weight_noalloc).
+ *    per device, one 32 MiB device array (psvae_linear_backward_weight_noalloc).
  *  - Work is enqueued on the hipStream_t passed as `stream` (a void* here so the
  *    header needs no HIP include); no entry point synchronises the device.
  *  - Return value: 0 = success; negative = PSVAE_E_* argument error detected on
@@ -292,7 +292,7 @@ size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg);
 /* psvae_linear_backward_weight without a scratch argument and without any allocation.  No counterpart in the
  * reference: it is for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  The slab partial sums of the split reduction go to a static device
- * array of psvae_noalloc_scratch_bytes() = 16 MiB that every GPU the library runs on holds until the process
+ * array of psvae_noalloc_scratch_bytes() = 32 MiB that every GPU the library runs on holds until the process
  * ends; a problem whose planned split needs more (nseg * splits * N * (K+1) floats) is refused with
  * PSVAE_E_STATIC_LIMIT.  Same kernels and same results, bit for bit, as psvae_linear_backward_weight given a
  * scratch buffer of psvae_linear_scratch_bytes.  All calls on one GPU share the array: calls that overlap there

@@ -10,7 +10,7 @@ extern "C" const char* psvae_strerror(int code) {
         case PSVAE_E_ALIGN: return "psvae: pointer or leading dimension violates an alignment rule (16 bytes / multiple of 4)";
         case PSVAE_E_WORKSPACE: return "psvae: workspace or scratch buffer too small";
         case PSVAE_E_CAPACITY: return "psvae: host output buffer too small";
-        case PSVAE_E_STATIC_LIMIT: return "psvae: the problem needs more scratch than the 16 MiB static array of the no-allocation entry point holds; use the variant that takes a scratch buffer";
+        case PSVAE_E_STATIC_LIMIT: return "psvae: the problem needs more scratch than the 32 MiB static array of the no-allocation entry point holds; use the variant that takes a scratch buffer";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -36,7 +36,8 @@ struct GemmP {
     int splits, rchunk;
     int relu, accumulate, ones_col;
     int a_vec, b_vec;
-    int to_slab;            // 1: raw partial sums to C + z*slab_stride (ldc = N)
+    int to_slab;            // 1: raw partial sums to C + z*slab_stride, rows ld_slab floats apart
+    int ld_slab;            // N, or N rounded up to 16 floats (160-tile kernel: 64-byte aligned row segments)
     long long slab_stride;
 };
 
@@ -654,9 +655,203 @@ __global__ __launch_bounds__(256) void gemm_dw_split_kernel(const GemmP p) {
 }
 #undef PSVAE_TR_READ
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same product on 160 x 160 output tiles: 6.25 times the matrix instructions per barrier, per operand byte
+// fetched and per workgroup prologue / epilogue of the 64 x 64 kernel, whose K-step (12 matrix instructions, 0.16 us of
+// matrix-pipe time) takes 0.6 us however its pieces are arranged.  160 divides the widths that matter here (300 + the
+// bias column -> 320, 150 -> 160, 600 -> 640) with the padding the 64-tiles have.  Each of the four waves owns 80 x 80
+// outputs as 5 x 5 tiles of v_mfma_f32_16x16x32_bf16: per K-step 60 transposed fragment reads feed 150 matrix
+// instructions (2400 cycles; the chip holds 1.5 - 1.9 GHz under them).  LDS image per operand: three planes
+// [32 reduction rows][160 outputs] of bf16, row pitch 320 bytes (the four rows a 16-lane group reads lie 16 banks
+// apart), two buffers: 120 KB, one workgroup per CU, one wave per SIMD.  Accumulators: 2 x 100 registers per lane (main
+// and small-term sums), held in the accumulator half of the register file.  Always writes slabs.
+// Measured at 95 k x 300 x 300: 105 us (154 TFLOP/s with the slab sum) against 166 us for the fp32 64-tile kernel and
+// 180 for the cut-operand one; with the cut left out 80 us, with the matrix instructions left out 55.
+constexpr int WD_T = 160, WD_PITCH = 2 * WD_T, WD_PLANE = BK * WD_PITCH, WD_OPER = 3 * WD_PLANE, WD_BUF = 2 * WD_OPER;
+constexpr int WD_Q = BK * (WD_T / 4) / 256;          // float4 quads per thread and operand tile: 5
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+typedef float floatx4w __attribute__((ext_vector_type(4)));
+struct WStage { float4 v[WD_Q]; };
+// A thread's quads of an operand tile: (row, column) never change, so the loads are "uniform tile base + 32-bit lane
+// offset".  Only a tile that overhangs the reduction range needs other offsets (rows past the end read the last
+// row, and are zeroed when cut): prepared once, chosen by a uniform select.
+struct WGeo { const char* X; long long step; int ones_d, r_part; unsigned off[WD_Q], offp[WD_Q]; };
+
+__device__ __forceinline__ WGeo wd_geo(const float* X, int ld, int o0, int o_lim, int ones_col, int r_lim, int r_last, int tid) {
+    WGeo g;
+    g.X = reinterpret_cast<const char*>(X); g.step = (long long)ld * 4;
+    g.ones_d = ones_col >= 0 ? ones_col - o0 : -(1 << 20);
+    g.r_part = r_last + BK > r_lim ? r_last : -1;
+    const int lim = ones_col >= 0 ? ones_col : o_lim;
+    const int safe = o0 < lim ? o0 : 0;          // (a tile that holds nothing but the ones column reads column 0)
+#pragma unroll
+    for (int u = 0; u < WD_Q; ++u) {
+        const int q = tid + 256 * u, row = q / (WD_T / 4), c = (q - row * (WD_T / 4)) * 4;
+        const int col = o0 + c < lim ? o0 + c : safe;             // a quad past the matrix reads the tile's first one (never used)
+        g.off[u] = (unsigned)(row * ld + col) * 4u;
+        g.offp[u] = (unsigned)(min(row, r_lim - 1 - r_last) * ld + col) * 4u;
+    }
+    return g;
+}
+__device__ __forceinline__ float4 wd_load_one(const WGeo& g, int u, int r0) {
+    const char* base = g.X + (long long)r0 * g.step;
+    return *reinterpret_cast<const float4*>(base + (r0 == g.r_part ? g.offp[u] : g.off[u]));
+}
+__device__ __forceinline__ WStage wd_load(const WGeo& g, int r0) {
+    WStage s;
+#pragma unroll
+    for (int u = 0; u < WD_Q; ++u) s.v[u] = wd_load_one(g, u, r0);
+    return s;
+}
+__device__ __forceinline__ floatx2 bf_widen(unsigned pair) {              // two bf16 -> two fp32
+    return floatx2{__uint_as_float(pair << 16), __uint_as_float(pair & 0xFFFF0000u)};
+}
+__device__ __forceinline__ void wd_cut_quad(char* plane0, int off, float4 v) {
+    const floatx2 a{v.x, v.y}, b{v.z, v.w};                              // (two-wide fp32 subtractions)
+    const unsigned h0 = bf_pair(a.x, a.y), h1 = bf_pair(b.x, b.y);
+    const floatx2 ra = a - bf_widen(h0), rb = b - bf_widen(h1);
+    const unsigned m0 = bf_pair(ra.x, ra.y), m1 = bf_pair(rb.x, rb.y);
+    const floatx2 sa = ra - bf_widen(m0), sb = rb - bf_widen(m1);
+    const unsigned l0 = bf_pair(sa.x, sa.y), l1 = bf_pair(sb.x, sb.y);
+    *reinterpret_cast<uintx2*>(plane0 + off) = uintx2{h0, h1};
+    *reinterpret_cast<uintx2*>(plane0 + WD_PLANE + off) = uintx2{m0, m1};
+    *reinterpret_cast<uintx2*>(plane0 + 2 * WD_PLANE + off) = uintx2{l0, l1};
+}
+// Quad u of a tile into the three planes.  Rows 8 .. 15 and 24 .. 31 of an image hold their 16-output tiles swapped
+// in pairs (byte offset ^ 32): the two 16-lane groups that a transposed read serves together read rows eight apart,
+// which would otherwise lie on the same banks.
+__device__ __forceinline__ void wd_cut_one(char* oper, float4 v, const WGeo& g, int u, int r0, int r_lim, int tid) {
+    const int q = tid + 256 * u, row = q / (WD_T / 4), c = (q - row * (WD_T / 4)) * 4;
+    const int d = g.ones_d - c;
+    v.x = d == 0 ? 1.f : v.x; v.y = d == 1 ? 1.f : v.y; v.z = d == 2 ? 1.f : v.z; v.w = d == 3 ? 1.f : v.w;
+    const bool ok = r0 + row < r_lim;
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    wd_cut_quad(oper, row * WD_PITCH + ((c * 2) ^ ((row & 8) << 2)), v);
+}
+__device__ __forceinline__ void wd_cut(char* oper, const WStage& s, const WGeo& g, int r0, int r_lim, int tid) {
+#pragma unroll
+    for (int u = 0; u < WD_Q; ++u) wd_cut_one(oper, s.v[u], g, u, r0, r_lim, tid);
+}
+// 8 consecutive reduction indices (8 (lane >> 4) .. + 7) of output (lane & 15) of a 16-output tile: two transposed reads
+__device__ __forceinline__ bf16x8 wd_frag(const char* p) {
+    typedef __attribute__((address_space(3))) shortx4 lds_shortx4;
+    const shortx4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(p));
+    const shortx4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(p + 4 * WD_PITCH));
+    typedef short shortx8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, shortx8{f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w});
+}
+
+__global__ __launch_bounds__(256) void gemm_dw_wide_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char sp_lds[];      // [2 buffers][A, B][3 planes][32][320 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // (tile order: see gemm_f32_kernel)
+    const unsigned gxy = gridDim.x * gridDim.y, nb = gxy * gridDim.z;
+    const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = bid & 7u, per = nb >> 3, rem = nb & 7u;
+    const unsigned tile = xcd * per + min(xcd, rem) + (bid >> 3);
+    const int z = tile / gxy, txy = tile - z * gxy;
+    const int tx = txy / gridDim.y, ty = txy - tx * gridDim.y;
+    const int seg = z / p.splits, sp = z - seg * p.splits;
+    const int m0 = tx * WD_T, n0 = ty * WD_T;
+    const int rbeg = sp * p.rchunk;
+    const int rend = min(p.R, rbeg + p.rchunk);
+    const int nk = (rend - rbeg + BK - 1) / BK;
+
+    // (An operand of the accumulator register class anywhere in the kernel makes the compiler keep the matrix
+    //  instructions' accumulators in the accumulator half of the register file - 200 of them here - instead of
+    //  treating that half as spill space for a 256-register allocation, which costs a copy in and out per instruction.)
+    asm volatile("; accumulators live in a[]" ::"a"(0.f));
+    floatx4w acc[5][5], lo[5][5];
+#pragma unroll
+    for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) { acc[rt][ct] = floatx4w{0.f, 0.f, 0.f, 0.f}; lo[rt][ct] = floatx4w{0.f, 0.f, 0.f, 0.f}; }
+
+    if (nk > 0) {
+        const int rlast = rbeg + (nk - 1) * BK;
+        const WGeo ga = wd_geo(p.A + seg * p.seg_a, p.lda, m0, p.M, -1, rend, rlast, tid);
+        const WGeo gb = wd_geo(p.B + seg * p.seg_b, p.ldb, n0, p.N, p.ones_col, rend, rlast, tid);
+        // lane 4 q + pp of a 16-lane group supplies reduction row q, outputs 4 pp .. + 3 of the group's 4 x 16 block;
+        // group g = lane >> 4 reads rows 8 g .. + 7 (the instruction's lane map: output l & 15, k = 8 (l >> 4) + j)
+        const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        const int lane_off = (8 * grp + q) * WD_PITCH + 8 * pp;
+        // Tile rt of the wave's five sits at byte y = 160 w + 32 rt of a row; in this group's rows it may be swapped with
+        // its neighbour (y ^ 32 = y + 32 or y - 32 by the parity of y / 32): two lane bases, for even and for odd rt.
+        const int swz = (grp & 1) << 5;                   // (this group's rows are 8 .. 15 or 24 .. 31 of the image)
+        const int a_sw = ((wm * 5) & 1) ? -swz : swz, b_sw = ((wn * 5) & 1) ? -swz : swz;
+        const int a_rd0 = lane_off + wm * 160 + a_sw, a_rd1 = lane_off + wm * 160 - a_sw;
+        const int b_rd0 = WD_OPER + lane_off + wn * 160 + b_sw, b_rd1 = WD_OPER + lane_off + wn * 160 - b_sw;
+        WStage sa = wd_load(ga, rbeg), sb = wd_load(gb, rbeg);
+        wd_cut(sp_lds, sa, ga, rbeg, rend, tid);
+        wd_cut(sp_lds + WD_OPER, sb, gb, rbeg, rend, tid);
+        sa = wd_load(ga, min(rbeg + BK, rlast));
+        sb = wd_load(gb, min(rbeg + BK, rlast));
+        __syncthreads();
+#define PSVAE_WD_TERM(ACC_, PA_, PB_)                                                                                    \
+        _Pragma("unroll") for (int rt = 0; rt < 5; ++rt)                                                                 \
+            ACC_[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt][PA_], fb[PB_], ACC_[rt][ct], 0, 0, 0);
+        // One register stage, each quad of it in flight for a whole step: while the 30 matrix instructions of column
+        // tile ct are issued, quad ct of either operand's NEXT tile (requested a step ago) is cut into the other
+        // buffer and its registers are reloaded with the tile after that.  A wave issues in order: the cut's ~350 vector
+        // instructions behind the 150 matrix instructions would add their time to the step; dealt out between them,
+        // two or three to a matrix instruction, they run in its shadow.
+        for (int t = 0; t < nk; ++t) {
+            const int cur = (t & 1) * WD_BUF, nxt = WD_BUF - cur;
+            const char* aa0 = sp_lds + cur + a_rd0;
+            const char* aa1 = sp_lds + cur + a_rd1;
+            const char* bb0 = sp_lds + cur + b_rd0;
+            const char* bb1 = sp_lds + cur + b_rd1;
+            const int r_cut = rbeg + (t + 1) * BK, r_ld = min(rbeg + (t + 2) * BK, rlast);     // (past the end: unused)
+            bf16x8 fa[5][3];
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) fa[rt][pc] = wd_frag(((rt & 1) ? aa1 : aa0) + pc * WD_PLANE + rt * 32);
+#pragma unroll
+            for (int ct = 0; ct < 5; ++ct) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) fb[pc] = wd_frag(((ct & 1) ? bb1 : bb0) + pc * WD_PLANE + ct * 32);
+                PSVAE_WD_TERM(lo, 2, 0) PSVAE_WD_TERM(lo, 0, 2) PSVAE_WD_TERM(lo, 1, 1)
+                PSVAE_WD_TERM(lo, 1, 0) PSVAE_WD_TERM(lo, 0, 1) PSVAE_WD_TERM(acc, 0, 0)
+                // (on the last step this writes an all-zero tile nobody reads)
+                wd_cut_one(sp_lds + nxt, sa.v[ct], ga, ct, r_cut, rend, tid);
+                wd_cut_one(sp_lds + nxt + WD_OPER, sb.v[ct], gb, ct, r_cut, rend, tid);
+                sa.v[ct] = wd_load_one(ga, ct, r_ld);
+                sb.v[ct] = wd_load_one(gb, ct, r_ld);
+#pragma unroll
+                for (int u = 0; u < 30; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    if (u % 5 == 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (u == 27 || u == 28) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+#undef PSVAE_WD_TERM
+    }
+    // slab: this lane holds column n0 + 80 wn + 16 ct + (lane & 15), rows m0 + 80 wm + 16 rt + 4 (lane >> 4) + i
+    float* C = p.C + (long long)z * p.slab_stride;
+#pragma unroll
+    for (int ct = 0; ct < 5; ++ct) {
+        const int j = n0 + wn * 80 + ct * 16 + (lane & 15);
+        if (j >= p.N) continue;
+#pragma unroll
+        for (int rt = 0; rt < 5; ++rt) {
+            const int i0 = m0 + wm * 80 + rt * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i0 + i < p.M) C[(long long)(i0 + i) * p.ld_slab + j] = acc[rt][ct][i] + lo[rt][ct][i];
+        }
+    }
+}
+
 // Sum `nz` slabs (fixed order z = 0..nz-1) and apply the epilogue.
 struct ReduceP {
-    const float* slabs; long long slab_stride; int nz;
+    const float* slabs; long long slab_stride; int nz, ld_slab;
     float* C; int ldc; long long seg_c;
     const float* bias; long long seg_bias;
     const float* mask; int ldmask; long long seg_mask;
@@ -669,14 +864,15 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
     const float* s = p.slabs + (long long)seg * p.nz * p.slab_stride;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e / p.N), j = (int)(e - (long long)i * p.N);
+        const long long o = (long long)i * p.ld_slab + j;
         float v = 0.f;
         int z = 0;
         for (; z + 4 <= p.nz; z += 4) {   // 4 independent loads in flight, summed in slab order
-            const float v0 = s[(long long)z * p.slab_stride + e], v1 = s[(long long)(z + 1) * p.slab_stride + e];
-            const float v2 = s[(long long)(z + 2) * p.slab_stride + e], v3 = s[(long long)(z + 3) * p.slab_stride + e];
+            const float v0 = s[(long long)z * p.slab_stride + o], v1 = s[(long long)(z + 1) * p.slab_stride + o];
+            const float v2 = s[(long long)(z + 2) * p.slab_stride + o], v3 = s[(long long)(z + 3) * p.slab_stride + o];
             v = (((v + v0) + v1) + v2) + v3;
         }
-        for (; z < p.nz; ++z) v += s[(long long)z * p.slab_stride + e];
+        for (; z < p.nz; ++z) v += s[(long long)z * p.slab_stride + o];
         if (p.bias) v += p.bias[seg * p.seg_bias + j];
         if (p.relu) v = fmaxf(v, 0.f);
         if (j == p.ones_col) {
@@ -710,12 +906,43 @@ Plan plan_splits(int M, int N, int R, int nseg) {
     return pl;
 }
 
+// The 160-tile weight-gradient kernel takes a product when its tiles pad the output no more than the 64-tiles do
+// (widths near a multiple of 160) and the reduction is long enough for every workgroup of the split to run
+// WIDE_MIN_STEPS K-steps.  One workgroup per CU (120 KB of LDS); the split aims at 128 workgroups: in the training
+// step these products run beside two other streams' kernels, which take the other CUs (128 against 256: +2.3 % on the
+// 128-graph step, +1 % at 256 graphs, equal at 1024; alone on the chip 256 is 40 % faster).  PSVAE_WIDE_GEMM=0 / 1
+// forces the kernel off / on (where the shape allows), PSVAE_WIDE_TARGET the workgroup count.
+constexpr int WIDE_MIN_STEPS = 4;
+Plan plan_wide(int M, int N, int R, int nseg) {
+    Plan none{0, 0};
+    static const int forced = [] { const char* e = getenv("PSVAE_WIDE_GEMM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int target = [] { const char* e = getenv("PSVAE_WIDE_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 128; }();
+    static const int min_steps = [] { const char* e = getenv("PSVAE_WIDE_MIN_STEPS"); return e && atoi(e) > 0 ? atoi(e) : WIDE_MIN_STEPS; }();
+    if (forced == 0) return none;
+    const long long tw = (long long)((M + WD_T - 1) / WD_T) * ((N + WD_T - 1) / WD_T), t64 = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (tw * WD_T * WD_T > t64 * BM * BN) return none;
+    const long long tiles = tw * nseg;
+    int want = (int)(target / tiles);
+    const int maxs = R / (min_steps * BK);
+    if (want > maxs) want = maxs;
+    if (want < 1 || (long long)want * tiles < 64) return none;       // too little work to fill a quarter of the chip
+    if ((long long)want * nseg < 2) return none;                     // (the kernel only writes slabs)
+    Plan pl;
+    pl.rchunk = (int)round_up((R + want - 1) / want, BK);
+    pl.splits = (R + pl.rchunk - 1) / pl.rchunk;
+    return pl;
+}
+
 }  // namespace
 
 size_t gemm_scratch_floats(int M, int N, int R, int nseg, bool sum_segments) {
     Plan pl = plan_splits(M, N, R, nseg);
-    const long long nz = (long long)nseg * pl.splits;
-    if (nz == 1 || (!sum_segments && pl.splits == 1)) return 0;
+    long long nz = (long long)nseg * pl.splits;
+    if (nz == 1 || (!sum_segments && pl.splits == 1)) nz = 0;
+    if (sum_segments) {                                              // (weight gradients: the 160-tile plan, if it is the larger)
+        const Plan pw = plan_wide(M, N, R, nseg);
+        return (size_t)std::max(nz * (long long)M * N, (long long)nseg * pw.splits * M * round_up(N, 16));
+    }
     return (size_t)(nz * (long long)M * N);
 }
 
@@ -755,7 +982,7 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
     p.a_vec = aligned16(d.A) && d.lda % 4 == 0 && d.seg_a % 4 == 0;
     p.b_vec = aligned16(d.B) && d.ldb % 4 == 0 && d.seg_b % 4 == 0;
     p.to_slab = slab ? 1 : 0;
-    p.slab_stride = (long long)d.M * d.N;
+    p.slab_stride = (long long)d.M * d.N; p.ld_slab = d.N;
     dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (unsigned)nz_total);
     if (grid.y > 65535 || grid.z > 65535) return PSVAE_E_SHAPE;
     const double flops = 2.0 * d.M * d.N * d.R * d.nseg;
@@ -770,15 +997,29 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
         } while (0)
         // the interleaved loop pays where a CU holds few workgroups (split reductions are planned for at most 512)
         const bool pipe = (long long)grid.x * grid.y * grid.z <= 1024;
-        // Weight gradients of aligned operands: the cut-operand kernel on the bf16 matrix instruction.  Its K-step is
-        // bound by LDS traffic (48 KB of transposed fragment reads per step: three planes per operand, each tile read
-        // by two waves), not by the matrix pipe and not by the cut (staging operands that arrive already cut changed
-        // nothing): per K-step it is on a par with the fp32 kernel (97 against 105 TFLOP/s at 95 k rows), but it needs
-        // 128 + 32 registers instead of 190 + 32 and shares a CU better with the other streams'
-        // kernels: +2 % on the 128-graph step, +1 % at 256 and 512 graphs, -1.5 % at 1024 (reductions over 19 k - 95 k rows
-        // there).  Used for reductions under 18 k rows;
+        // Weight gradients of aligned operands: the cut-operand kernels on the bf16 matrix instruction.  Shapes the
+        // 160-tiles fit (plan_wide) go to that kernel.  For the rest, the 64-tile cut-operand kernel runs a K-step in
+        // the time the fp32 kernel needs (97 against 105 TFLOP/s at 95 k rows) but with 128 + 32 registers instead of
+        // 190 + 32 it shares a CU better with the other streams' kernels: +2 % on the 128-graph step, +1 % at 256 and
+        // 512 graphs, -1.5 % at 1024 (reductions over 19 k - 95 k rows there).  Used for reductions under 18 k rows;
         // PSVAE_SPLIT_GEMM=0 / 1 forces fp32 / cut operands.
         static const int split_forced = [] { const char* e = getenv("PSVAE_SPLIT_GEMM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+        const Plan pw = (d.a_t && d.b_t && vec && d.sum_segments) ? plan_wide(d.M, d.N, d.R, d.nseg) : Plan{0, 0};
+        if (pw.splits > 0 && d.scratch && d.scratch_floats >= (size_t)d.nseg * pw.splits * d.M * round_up(d.N, 16)) {
+            static bool wide_attr_set = false;
+            if (!wide_attr_set) {
+                if (hipFuncSetAttribute((const void*)gemm_dw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WD_BUF) != hipSuccess)
+                    return (int)hipGetLastError();
+                wide_attr_set = true;
+            }
+            pl = pw;
+            nz_total = (long long)d.nseg * pl.splits;
+            slab = true;
+            p.C = d.scratch; p.to_slab = 1; p.splits = pl.splits; p.rchunk = pl.rchunk;
+            p.ld_slab = (int)round_up(d.N, 16); p.slab_stride = (long long)d.M * p.ld_slab;
+            const dim3 wgrid((d.M + WD_T - 1) / WD_T, (d.N + WD_T - 1) / WD_T, (unsigned)nz_total);
+            hipLaunchKernelGGL(gemm_dw_wide_kernel, wgrid, dim3(256), 2 * WD_BUF, s, p);
+        } else
         if (d.a_t && d.b_t && vec && (split_forced >= 0 ? split_forced == 1 : d.R < 18432)) {
             static bool attr_set = false;
             if (!attr_set) {
@@ -797,7 +1038,7 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
     PSVAE_LAUNCH_CHECK();
     if (slab) {
         ReduceP r;
-        r.slabs = d.scratch; r.slab_stride = p.slab_stride;
+        r.slabs = d.scratch; r.slab_stride = p.slab_stride; r.ld_slab = p.ld_slab;
         r.nz = d.sum_segments ? (int)nz_total : pl.splits;
         r.C = d.C; r.ldc = d.ldc; r.seg_c = d.seg_c;
         r.bias = d.bias; r.seg_bias = d.seg_bias;
@@ -846,11 +1087,12 @@ int linear_bwd_w(hipStream_t s, const float* dy, int lddy, int64_t seg_dy, const
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient without any allocation: the slab partial sums of the split reduction live in a file-scope device
 // array instead of a caller-supplied scratch buffer, for callers that cannot allocate (HIP graph capture, serving
-// loops, harnesses that forbid hipMalloc).  Every GPU the library runs on holds its own copy of the array (16 MiB)
+// loops, harnesses that forbid hipMalloc).  Every GPU the library runs on holds its own copy of the array (32 MiB:
+// the largest split the 160-tile kernel plans, 256 slabs of 160 x 160, always fits)
 // until the process ends.  In host code the array's NAME is only a stand-in: the device address is asked for once
 // per device with hipGetSymbolAddress and kept; kernels are given that address.
 namespace {
-constexpr size_t NOALLOC_SCRATCH_FLOATS = (size_t)4 << 20;       // 16 MiB
+constexpr size_t NOALLOC_SCRATCH_FLOATS = (size_t)8 << 20;       // 32 MiB
 __device__ __align__(256) float scratch[NOALLOC_SCRATCH_FLOATS];
 float* noalloc_ptr[64] = {};
 std::mutex noalloc_mu;

@@ -340,10 +340,15 @@ def test_scorer_fused_forward(S, n, B):
 
 
 @pytest.mark.parametrize('nseg,M,N,K,bias', [(4, 5000, 300, 300, True), (1, 24000, 328, 656, True), (1, 17000, 656, 328, False),
-                                             (2, 9000, 64, 200, True), (1, 16400, 600, 100, True), (1, 16384 + 7, 160, 160, True)])
+                                             (2, 9000, 64, 200, True), (1, 16400, 600, 100, True), (1, 16384 + 7, 160, 160, True),
+                                             # widths the 160 x 160 tiles fit: node_trans (600 x 150 + bias), a reduction
+                                             # that ends inside a K-step, tiles that are full / hold only the bias column
+                                             (1, 2968, 600, 150, True), (1, 7001, 300, 152, False), (1, 4999, 320, 319, True),
+                                             (2, 1403, 160, 160, True), (3, 999, 480, 159, True)])
 def test_weight_gradient_over_long_reductions(nseg, M, N, K, bias):
     """dw = sum over segments of dy^T x (and db = column sums of dy) where the reduction runs over tens of
-    thousands of rows: the 160 x 160-tile kernel with its slab sum, against a float64 product."""
+    thousands of rows (split reductions with their slab sum; the 64 x 64 and the 160 x 160 tile kernels), against a
+    float64 product."""
     from ps_vae_amd import _lib
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream

@@ -10,7 +10,10 @@ from ps_vae_amd import _lib  # noqa: E402
 from tools.gemm_bench import timeit  # noqa: E402
 
 L = _lib.lib(); dev = torch.device('cuda:0'); st = torch.cuda.current_stream().cuda_stream
-for M, N, K in [(95000, 300, 300), (95000, 320, 320), (95000, 256, 256), (11856, 300, 300)]:
+shapes = [(95000, 300, 300), (95000, 320, 320), (95000, 256, 256), (11856, 300, 300)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+for M, N, K in shapes:
     x = torch.randn(M, K, device=dev); dy = torch.randn(M, N, device=dev)
     dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
     sc = torch.empty(max(L.psvae_linear_scratch_bytes(M, N, K, 1), 256), dtype=torch.uint8, device=dev)
