@@ -293,7 +293,8 @@ size_t psvae_linear_scratch_bytes(int M, int N, int K, int nseg);
  * reference: it is for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  The slab partial sums of the split reduction go to a static device
  * array of psvae_noalloc_scratch_bytes() = 32 MiB that every GPU the library runs on holds until the process
- * ends; a problem whose planned split needs more (nseg * splits * N * (K+1) floats) is refused with
+ * ends; a problem whose planned split needs more (nseg * splits * N * (K+1) floats, K+1 rounded up to 16 where the
+ * 160-tile kernel takes the product) is refused with
  * PSVAE_E_STATIC_LIMIT.  Same kernels and same results, bit for bit, as psvae_linear_backward_weight given a
  * scratch buffer of psvae_linear_scratch_bytes.  All calls on one GPU share the array: calls that overlap there
  * (two streams, two host threads) race; calls on one stream do not. */

@@ -13,7 +13,7 @@ import sys
 
 CLASSES = [  # (substring of the kernel name, kernel class as bench.py reports it)
     ('gemm_f32_kernel<false, false', 'gemm_forward'), ('gemm_f32_kernel<false, true', 'gemm_input_grad'),
-    ('gemm_f32_kernel<true,', 'gemm_weight_grad'), ('gemm_dw_split_kernel', 'gemm_weight_grad'), ('gemm_reduce_kernel', 'gemm_slab_reduce'),
+    ('gemm_f32_kernel<true,', 'gemm_weight_grad'), ('gemm_dw_split_kernel', 'gemm_weight_grad'), ('gemm_dw_wide_kernel', 'gemm_weight_grad'), ('gemm_reduce_kernel', 'gemm_slab_reduce'),
     ('gine_agg_fwd_kernel', 'gine_aggregate_fwd'), ('gine_agg_bwd_kernel', 'gine_aggregate_bwd'),
     ('gine_etab_reduce_kernel', 'gine_edge_grad'), ('embed3_gather_kernel', 'embed_gather'), ('rows_gather_kernel', 'embed_gather'),
     ('table_grad_', 'table_grad'), ('segment_pool_kernel', 'segment_pool'), ('pair_gather_kernel', 'pair_gather'),
