@@ -763,24 +763,49 @@ __device__ __forceinline__ void flb_product(const char* img, int PB, int plane, 
     // of fp32 multiply-adds rounds, not six times as often.
     floatx4 lo[RT][CT];
     fl_zero<CT, RT>(lo);
-#define FLB_MFMA(A_, B_)                                                                                    \
+    // One block's matrix instructions with the loads of the block two ahead dealt in between them: a wave issues in
+    // order, and the packed weights arrive through the CU's vector-memory path at about the rate the matrix pipe
+    // consumes them (a 1-KiB wave load per four to six matrix instructions), so requests queued behind a block's
+    // instructions leave the pipe idle while they are issued.  The piece products are ordered so that a plane of the
+    // weights is free as early as possible: l first (one product), then m (two), then h (three); each plane's
+    // registers are reloaded right behind its last product.
+#define FLB_LOADP(B_, KB_, P_)                                                                              \
     {                                                                                                       \
-        FLB_TERM(lo, A_, 2, B_, 0) FLB_TERM(lo, A_, 0, B_, 2) FLB_TERM(lo, A_, 1, B_, 1)                    \
-        FLB_TERM(lo, A_, 1, B_, 0) FLB_TERM(lo, A_, 0, B_, 1) FLB_TERM(acc, A_, 0, B_, 0)                   \
+        const char* p_ = wlane + (size_t)min((KB_), KB - 1) * (3 * 4 * Npad * 16);                          \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                   \
+            B_[P_][ct] = fl_ld16(p_ + ((size_t)(P_) * 4 * Npad + ct * 16) * 16);                            \
     }
+#define FLB_MFMA(A_, B_, KBN_)                                                                              \
+    {                                                                                                       \
+        FLB_TERM(lo, A_, 0, B_, 2) FLB_LOADP(B_, KBN_, 2)                                                   \
+        FLB_TERM(lo, A_, 1, B_, 1) FLB_TERM(lo, A_, 0, B_, 1) FLB_LOADP(B_, KBN_, 1)                        \
+        FLB_TERM(lo, A_, 2, B_, 0) FLB_TERM(lo, A_, 1, B_, 0) FLB_TERM(acc, A_, 0, B_, 0) FLB_LOADP(B_, KBN_, 0) \
+        __builtin_amdgcn_sched_group_barrier(0x008, RT * CT, 0);                                            \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT, 0);                                         \
+        }                                                                                                   \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * RT, 0);                                         \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);                                                 \
+    }
+    // Everything requested so far - the two prefetched blocks and whatever the phase in front of the product left in
+    // flight - is waited for HERE, once: a wait in the loop is one instruction for the first and for every later
+    // iteration, and with older requests pending on entry the compiler sizes it for those (all but one load complete),
+    // which in every later iteration exposes the latency of the block requested half an iteration earlier.
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
     FLB_READA(a0, 0)
     __builtin_amdgcn_sched_barrier(0);
-    for (int kb = 0; kb < KB; kb += 2) {        // (the guards are uniform and hold no loads)
+    for (int kb = 0; kb < KB; kb += 2) {        // (the guards are uniform and hold no loads the next block needs)
         FLB_READA(a1, kb + 1)
         __builtin_amdgcn_sched_barrier(0);
-        FLB_MFMA(a0, b0)
+        FLB_MFMA(a0, b0, kb + 2)
         __builtin_amdgcn_sched_barrier(0);
-        FLB_LOADB(b0, kb + 2)
         FLB_READA(a0, kb + 2)
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 1 < KB) FLB_MFMA(a1, b1)
-        __builtin_amdgcn_sched_barrier(0);
-        FLB_LOADB(b1, kb + 3)
+        if (kb + 1 < KB) FLB_MFMA(a1, b1, kb + 3)
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -788,6 +813,7 @@ __device__ __forceinline__ void flb_product(const char* img, int PB, int plane, 
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += lo[rt][ct];
 #undef FLB_MFMA
+#undef FLB_LOADP
 #undef FLB_TERM
 #undef FLB_READA
 #undef FLB_LOADB
