@@ -311,7 +311,7 @@ int stacks_edge_grads(hipStream_t st, const Sz& s, const WS& w, const Stack* k, 
 // products run beside the input-gradient chain.  Fork and join are event waits on the
 // caller's stream, so from outside the call still behaves like work on that one stream.
 // Set PSVAE_STREAMS=0 to run everything on the caller's stream.
-struct Lanes { hipStream_t s1, s2; hipEvent_t ev[16]; };
+struct Lanes { hipStream_t s1, s2; hipEvent_t ev[17]; };
 std::mutex lanes_mu;
 Lanes* lanes_per_device[64] = {};
 int lanes_disabled = -1;
@@ -362,7 +362,7 @@ Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
         }
         for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
         if (probe && getenv("PSVAE_STREAMS_DEBUG")) fprintf(stderr, "psvae_streams_init: device %d, %d side stream(s) replaced\n", dev, nrej);
-        for (int i = 0; ok && i < 16; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < 17; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { delete l; lanes_disabled = 1; return nullptr; }
         lanes_per_device[dev] = l;
     }
@@ -590,8 +590,11 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     if ((long long)s.B * s.Z <= SMALL_LINEAR_OUTPUTS) PSVAE_TRY(small_linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z));
     else PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
+    // (dz_piece is what the caller's stream waits for in front of the latent head; the piece-embedding gradient the
+    //  next product feeds is not needed before the embedding tables, at the end of the step)
+    if (L && hipEventRecord(L->ev[2], s1) != hipSuccess) return (int)hipGetLastError();   // dz_piece ready
     PSVAE_TRY(linear_bwd_x(s1, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
-    if (L && hipEventRecord(L->ev[2], s1) != hipSuccess) return (int)hipGetLastError();   // dz_piece, dsemb ready
+    if (L && hipEventRecord(L->ev[16], s1) != hipSuccess) return (int)hipGetLastError();  // dsemb ready
     PSVAE_TRY(linear_bwd_w(s1, w.logits, s.ldl, 0, w.hseq, s.R, 0, 1, g.vocab_w, g.vocab_b, s.BT, s.V2, s.R, sc1, scf));
     PSVAE_TRY(linear_bwd_w(s1, w.dgh, 3 * s.R, 0, w.hprev, s.R, 0, 1, g.gru_whh, g.gru_bhh, s.BT, 3 * s.R, s.R, sc1, scf));
     PSVAE_TRY(linear_bwd_w(s1, w.dgi, 3 * s.R, 0, w.semb, s.Dp, 0, 1, g.gru_wih, g.gru_bih, s.BT, 3 * s.R, s.Dp, sc1, scf));
@@ -754,6 +757,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
         {g.piece_emb, d.num_piece, s.Dp, b.piece_rows_ptr, b.piece_rows_idx, w.dX0, s.Din, s.Da,
          b.seq_rows_ptr, b.seq_rows_idx, w.dsemb, s.Dp, 0},
         {g.pos_emb, d.max_pos, s.Dq, b.pos_rows_ptr, b.pos_rows_idx, w.dX0, s.Din, s.Da + s.Dp, nullptr, nullptr, nullptr, 0, 0}};
+    if (L && hipStreamWaitEvent(st, L->ev[16], 0) != hipSuccess) return (int)hipGetLastError();
     PSVAE_TRY(table_grads(st, tg, 3, w.tg_part, w.tg_part_floats));
     if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[10])); PSVAE_TRY(hand_over(s2, st, L->ev[11])); }
     return 0;
