@@ -920,7 +920,11 @@ Plan plan_wide(int M, int N, int R, int nseg) {
     static const int min_steps = [] { const char* e = getenv("PSVAE_WIDE_MIN_STEPS"); return e && atoi(e) > 0 ? atoi(e) : WIDE_MIN_STEPS; }();
     if (forced == 0) return none;
     const long long tw = (long long)((M + WD_T - 1) / WD_T) * ((N + WD_T - 1) / WD_T), t64 = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    if (tw * WD_T * WD_T > t64 * BM * BN) return none;
+    // (over long reductions the 160-tiles run a padded flop 1.5 x faster than the fp32 64-tile kernel that would take
+    //  the product otherwise, so up to 30 % more padding than the 64-tiles' still pays: node_trans, 600 x 201)
+    static const int long_r = [] { const char* e = getenv("PSVAE_WIDE_LONG_R"); return e ? atoi(e) : 12288; }();
+    const long long padw = tw * WD_T * WD_T, pad64 = t64 * BM * BN;
+    if (padw > pad64 && !(long_r > 0 && R >= long_r && padw * 10 <= pad64 * 13)) return none;
     const long long tiles = tw * nseg;
     int want = (int)(target / tiles);
     const int maxs = R / (min_steps * BK);
