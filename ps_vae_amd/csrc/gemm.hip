@@ -907,24 +907,31 @@ Plan plan_splits(int M, int N, int R, int nseg) {
 }
 
 // The 160-tile weight-gradient kernel takes a product when its tiles pad the output no more than the 64-tiles do
-// (widths near a multiple of 160) and the reduction is long enough for every workgroup of the split to run
-// WIDE_MIN_STEPS K-steps.  One workgroup per CU (120 KB of LDS); the split aims at 128 workgroups: in the training
-// step these products run beside two other streams' kernels, which take the other CUs (128 against 256: +2.3 % on the
-// 128-graph step, +1 % at 256 graphs, equal at 1024; alone on the chip 256 is 40 % faster).  PSVAE_WIDE_GEMM=0 / 1
-// forces the kernel off / on (where the shape allows), PSVAE_WIDE_TARGET the workgroup count.
+// (widths near a multiple of 160; more padding is accepted over long reductions, see plan_wide) and the reduction is
+// long enough for every workgroup of the split to run WIDE_MIN_STEPS K-steps.  One workgroup per CU (120 KB of LDS);
+// the split aims at 128 workgroups: in the training step these products run beside two other streams' kernels, which
+// take the other CUs (128 against 256: +2.3 % on the 128-graph step, +1 % at 256 graphs, equal at 1024; alone on the
+// chip 256 is 40 % faster).  PSVAE_WIDE_GEMM=0 / 1 forces the kernel off / on (where the shape allows),
+// PSVAE_WIDE_TARGET the workgroup count, PSVAE_WIDE_PAD_PCT the padding allowed (percent of the 64-tiles').
 constexpr int WIDE_MIN_STEPS = 4;
 Plan plan_wide(int M, int N, int R, int nseg) {
     Plan none{0, 0};
     static const int forced = [] { const char* e = getenv("PSVAE_WIDE_GEMM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    static const int target = [] { const char* e = getenv("PSVAE_WIDE_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 128; }();
+    static const int target_forced = [] { const char* e = getenv("PSVAE_WIDE_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
     static const int min_steps = [] { const char* e = getenv("PSVAE_WIDE_MIN_STEPS"); return e && atoi(e) > 0 ? atoi(e) : WIDE_MIN_STEPS; }();
+    static const int pad_forced = [] { const char* e = getenv("PSVAE_WIDE_PAD_PCT"); return e && atoi(e) >= 100 ? atoi(e) : 0; }();
     if (forced == 0) return none;
     const long long tw = (long long)((M + WD_T - 1) / WD_T) * ((N + WD_T - 1) / WD_T), t64 = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    // (over long reductions the 160-tiles run a padded flop 1.5 x faster than the fp32 64-tile kernel that would take
-    //  the product otherwise, so up to 30 % more padding than the 64-tiles' still pays: node_trans, 600 x 201)
-    static const int long_r = [] { const char* e = getenv("PSVAE_WIDE_LONG_R"); return e ? atoi(e) : 12288; }();
-    const long long padw = tw * WD_T * WD_T, pad64 = t64 * BM * BN;
-    if (padw > pad64 && !(long_r > 0 && R >= long_r && padw * 10 <= pad64 * 13)) return none;
+    // Padding the 160-tiles may add over the 64-tiles': none for short reductions, 30 % from 12 k rows (node_trans,
+    // 600 x 201), and 60 % from 18 432 rows on, where the kernel that would take the product otherwise is the fp32
+    // one: the 160-tiles beat it by 1.5 x per padded flop alone and by more beside other kernels (they hold 128 - 192
+    // CUs, it floods all of them).  That puts the link scorer's 656 x 329, 328 x 329 and 328 x 657 on them from 768
+    // graphs per step (+1 %; +1.7 % at 1024), together with a split for 192 workgroups instead of 128 (+1.5 % more at
+    // 1024).  From 10 k rows on the same rule loses 1 % at 512 graphs.  PSVAE_WIDE_R160 moves the row count.
+    static const int r160 = [] { const char* e = getenv("PSVAE_WIDE_R160"); return e && atoi(e) > 0 ? atoi(e) : 18432; }();
+    const int pad_pct = pad_forced ? pad_forced : (R >= r160 ? 160 : (R >= 12288 ? 130 : 100));
+    if (tw * WD_T * WD_T * 100 > t64 * BM * BN * pad_pct) return none;
+    const int target = target_forced ? target_forced : (R >= r160 ? 192 : 128);
     const long long tiles = tw * nseg;
     int want = (int)(target / tiles);
     const int maxs = R / (min_steps * BK);
