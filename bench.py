@@ -69,15 +69,56 @@ def make_batches(tok, vocab, shape, batch_size, count, seed, host_times=None):
     return out, t_collate / count
 
 
-def _cpu_model():
+def _cpu_info():
+    """(exact `model name` string, physical cores of the first socket, CPUs this process may use) from /proc/cpuinfo,
+    the affinity mask and the cgroup's CPU quota."""
+    model, cores, phys, core = 'unknown', set(), None, None
     try:
         with open('/proc/cpuinfo') as f:
             for line in f:
-                if line.startswith('model name'):
-                    return line.split(':', 1)[1].strip()
+                key, _, val = line.partition(':')
+                key, val = key.strip(), val.strip()
+                if key == 'model name' and model == 'unknown':
+                    model = val
+                elif key == 'physical id':
+                    phys = val
+                elif key == 'core id':
+                    core = val
+                elif key == '' and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
     except OSError:
         pass
-    return 'unknown'
+    first = min((p for p, _ in cores), default=None)
+    socket_cores = len({c for p, c in cores if p == first}) or (os.cpu_count() or 1)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+            if quota != 'max':
+                usable = min(usable, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return model, socket_cores, usable
+
+
+def gpus_without_touching_hip():
+    """GPU count of this node from the kernel driver's topology files (agents with SIMDs): the process that
+    starts the ranks must not initialise the HIP runtime itself.  None when the files cannot be read."""
+    import glob
+    n, seen = 0, False
+    for path in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+        try:
+            with open(path) as f:
+                seen = True
+                for line in f:
+                    if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError, IndexError):
+            continue
+    return n if seen else None
 
 
 def _time_oracle(cpu_batch, vocab, budget_s, max_steps):
@@ -94,18 +135,108 @@ def _time_oracle(cpu_batch, vocab, budget_s, max_steps):
     return B, n, time.perf_counter() - t0
 
 
-def cpu_baseline(cpu_batch, qm9_batch, vocab, budget_s=12.0, max_steps=8):
-    """The CPU oracle's training step (the reference's op sequence in plain PyTorch) on the host cores:
-    the benchmark's own batch, and the reference's CPU-runnable case (QM9-shape, 32 graphs) beside it."""
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    B, n, dt = _time_oracle(cpu_batch, vocab, budget_s, max_steps)
-    Bq, nq, dtq = _time_oracle(qm9_batch, vocab, 4.0, 30)
-    return {'value': B * n / dt, 'unit': 'molecules/s', 'cores': threads, 'kind': 'port', 'cpu_model': _cpu_model(),
-            'sample': f'{n} training steps of the CPU oracle on one batch of {B} synthetic ZINC-shape graphs '
-                      f'({dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU)',
-            'qm9_b32': {'value': Bq * nq / dtq, 'unit': 'molecules/s',
-                        'sample': f'{nq} steps on one batch of {Bq} QM9-shape graphs ({dtq / nq * 1e3:.1f} ms/step)'}}
+def cpu_baseline(cpu_batch, qm9_batch, vocab, budget_s=7.0, max_steps=8):
+    """The CPU oracle's training step (the reference's op sequence in plain PyTorch) on the host cores, at two thread
+    counts: 8, and the physical cores of one socket - as far as this process may use them (its affinity mask and
+    cgroup quota; more threads than that only queue behind each other).  The benchmark's own batch, and the
+    reference's CPU-runnable case (QM9-shape, 32 graphs) beside it.  The headline `value` is the better of the two."""
+    model_name, socket_cores, usable = _cpu_info()
+    runs = []
+    for threads in sorted({min(8, usable), min(socket_cores, usable)}):
+        torch.set_num_threads(threads)
+        B, n, dt = _time_oracle(cpu_batch, vocab, budget_s, max_steps)
+        Bq, nq, dtq = _time_oracle(qm9_batch, vocab, 2.5, 30)
+        runs.append({'cores': threads, 'value': B * n / dt, 'unit': 'molecules/s',
+                     'sample': f'{n} training steps of the CPU oracle on one batch of {B} synthetic ZINC-shape graphs '
+                               f'({dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU)',
+                     'qm9_b32': {'value': Bq * nq / dtq, 'unit': 'molecules/s',
+                                 'sample': f'{nq} steps on one batch of {Bq} QM9-shape graphs ({dtq / nq * 1e3:.1f} ms/step)'}})
+    best = max(runs, key=lambda r: r['value'])
+    return {'value': best['value'], 'unit': 'molecules/s', 'cores': best['cores'], 'kind': 'port', 'cpu_model': model_name,
+            'physical_cores_per_socket': socket_cores, 'cpus_usable_by_this_process': usable,
+            'sample': best['sample'], 'qm9_b32': best['qm9_b32'], 'runs': runs,
+            'note': 'torch_geometric cannot be installed here (no network): the oracle restates GINEConv with '
+                    'index_select + index_add_, everything else is the op sequence of the reference modules'}
+
+
+def step_flops(sz, dm, backward=True):
+    """Algorithmic flops of one training step over a batch of these sizes (products only, 2 flops per multiply-add):
+    both GINE stacks (node_trans + t applications of the two-layer MLP), pooling head, latent head, GRU + vocabulary
+    logits, link scorer, property head; backward counts twice the forward (input and weight gradients)."""
+    n, B, S, T = sz['n'], sz['B'], sz['S'], sz['L'] - 1
+    H, G, Z, R = dm.hidden, dm.graph, dm.latent, dm.rnn
+    Din, Dp, V2 = dm.d_atom + dm.d_piece + dm.d_pos, dm.d_piece, dm.num_piece
+    P, P2 = 2 * H + Z, (2 * H + Z) // 2
+    stacks = n * (2.0 * Din * H * 2 + (dm.t_enc + dm.t_dec) * 4.0 * H * H)
+    heads = B * (2.0 * dm.t_enc * H * G + 4.0 * G * Z + 2.0 * Z * R)
+    piece = B * T * (6.0 * R * (Dp + R) + 2.0 * R * V2)
+    scorer = S * 2.0 * (P * P2 + P2 * P2 + P2 * P + 4.0 * P)
+    pred = B * 2.0 * (Z * dm.pred_hidden + dm.pred_hidden ** 2 + dm.pred_hidden * dm.n_props)
+    fwd = stacks + heads + piece + scorer + pred
+    return fwd * (3.0 if backward else 1.0)
+
+
+def encode_bulk(dev, graphs=4096, calls=10):
+    """Bulk latent encoding (`PSVAEModel.encode` = the deterministic part of `get_z`) in batches of 4096 ZINC-shape
+    graphs: the encoder-only configuration of the benchmark list (1 M graphs = 245 such calls)."""
+    V = 300
+    tok = Tokenizer.synthetic(V)
+    torch.manual_seed(2021)
+    model = PSVAEModel(full_config(default_args(), tok), tok).to(dev)
+    random.seed(1)
+    ds = PackedMolDataset(synth.make_molecules(11, 'zinc', V, 2 * graphs), tok)
+    t = time.perf_counter()
+    batches = [ds.collate_fn(list(range(i * graphs, (i + 1) * graphs))) for i in range(2)]
+    host_ms = (time.perf_counter() - t) / 2 * 1e3
+    batches = [to_device(b, dev) for b in batches]
+    for b in batches:
+        model.encode(b)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(calls):
+        model.encode(batches[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / calls
+    sz, dm = batches[0]['_native'].sizes, model._dims
+    H, Din = dm.hidden, dm.d_atom + dm.d_piece + dm.d_pos
+    flops = sz['n'] * (2.0 * Din * H + dm.t_enc * 4.0 * H * H) + graphs * (2.0 * dm.t_enc * H * dm.graph + 4.0 * dm.graph * dm.latent)
+    return {'workload': f'encoder-only latent encoding, {graphs} ZINC-shape graphs per call ({sz["n"]} atoms, {sz["E"]} directed bonds), '
+                        'vocab 300, hidden 300', 'calls': calls, 'ms_per_call': dt * 1e3, 'value': graphs / dt, 'unit': 'graphs/s',
+            'seconds_per_million_graphs': 1e6 / (graphs / dt), 'TFLOPs': flops / dt / 1e12,
+            'frac_fp32_mfma_peak': flops / dt / 1e12 / MFMA_F32_PEAK_TF, 'host_collate_ms_per_batch_packed_dataset': host_ms}
+
+
+def stress_config(dev, steps=5):
+    """The stress configuration of the benchmark list: 32 graphs of 60 atoms, 8 GINE iterations in both stacks, hidden
+    512 (link scorer 1080 -> 540 -> 540 -> 1080 -> 4), EVERY cross-piece pair scored; one full training step."""
+    V, B = 300, 32
+    tok = Tokenizer.synthetic(V)
+    torch.manual_seed(2021)
+    cfg = full_config(default_args(node_hidden_dim=512), tok)
+    cfg['encoder']['t'] = 8
+    cfg['vae_piece_decoder']['t'] = 8
+    model = PSVAEModel(cfg, tok).to(dev)
+    opt = model.configure_optimizers()
+    ds = PackedMolDataset(synth.make_molecules(12, 'stress', V, 2 * B), tok)
+    batches = [to_device(ds.collate_fn(list(range(i * B, (i + 1) * B)), all_pairs=True), dev) for i in range(2)]
+
+    def step(i):
+        opt.zero_grad()
+        model.train_step(batches[i % 2], opt)
+        model.global_step += 1
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    sz = batches[0]['_native'].sizes
+    flops = step_flops(sz, model._dims)
+    return {'workload': f'training step, {B} graphs x 60 atoms, hidden 512, 8 GINE iterations per stack, all {sz["S"]} cross-piece '
+                        'pairs scored, vocab 300', 'steps': steps, 'ms_per_step': dt * 1e3, 'value': B / dt, 'unit': 'graphs/s',
+            'GFLOP_per_step': flops / 1e9, 'TFLOPs': flops / dt / 1e12, 'frac_fp32_mfma_peak': flops / dt / 1e12 / MFMA_F32_PEAK_TF}
 
 
 def device_collate_ms(mols, tok, dev, batch_size, iters=20):
@@ -356,19 +487,24 @@ class Leg:
         elapsed = time.perf_counter() - t0
         final = loss.detach().double().reshape(1).clone()
         if self.dist_on:
-            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            # (host tensors: gloo's own path for device tensors stalls when ranks share a GPU; RCCL is given device tensors)
+            on_dev = torch.distributed.get_backend() == 'nccl'
+            t = torch.tensor([elapsed], device=self.dev if on_dev else 'cpu', dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t)
             # a rank's loss is its share of the global batch's loss (local sums over global counts)
+            final = final if on_dev else final.cpu()
             torch.distributed.all_reduce(final, op=torch.distributed.ReduceOp.SUM)
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)) if not os.environ.get('PSVAE_BENCH_NO_MARKS') else [elapsed / steps * 1e3] * steps
         spread = {'median': per_step[len(per_step) // 2], 'p10': per_step[int(0.1 * (len(per_step) - 1))],
                   'p90': per_step[int(0.9 * (len(per_step) - 1))]}
         if self.model.recurrence_gave_up():
-            raise SystemExit('the multi-CU GRU recurrence timed out during the run: results are invalid')
+            raise SystemExit('a step reported invalid results during the run')
         self.next_step = warmup + steps
         return {'elapsed': elapsed, 'ms_per_step': elapsed / steps * 1e3, 'value': self.global_batch * steps / elapsed,
-                'step_ms': spread, 'host_enqueue_ms_per_step': host_enqueue_s / steps * 1e3, 'final_loss': float(final)}
+                'step_ms': spread, 'host_enqueue_ms_per_step': host_enqueue_s / steps * 1e3, 'final_loss': float(final),
+                # recurrences redone on one compute unit after the multi-CU kernels stopped waiting (0 on a GPU of our own)
+                'gru_recurrences_redone': self.model.recurrence_redone()}
 
 
 def main():
@@ -387,14 +523,18 @@ def main():
                          '"strong_scaling" (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bulk', action='store_true', help='skip the aggregation kernels at the bulk-encoding size')
+    ap.add_argument('--no-configs', action='store_true', help='skip the encoder-only (4096 graphs per call) and stress '
+                    '(60 atoms, hidden 512, 8 iterations, all pairs) configurations')
     ap.add_argument('--profile-steps', type=int, default=10)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' rehearses the multi-rank "
                     "path on a box with fewer GPUs than ranks (ranks then share devices)")
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # no launcher around us: start the ranks here, before anything in this process touches a GPU
-        if args.backend == 'nccl' and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f'{args.gpus} ranks over RCCL need {args.gpus} GPUs, this node shows {torch.cuda.device_count()} '
+        # (counted from the driver's topology files: this process must not initialise HIP; the ranks check again)
+        n_gpus = gpus_without_touching_hip()
+        if args.backend == 'nccl' and n_gpus is not None and n_gpus < args.gpus:
+            raise SystemExit(f'{args.gpus} ranks over RCCL need {args.gpus} GPUs, this node shows {n_gpus} '
                              "(--backend gloo rehearses the multi-rank path on fewer)")
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     # The result line is the ONLY thing this program writes to its standard output: libraries that chat on file
@@ -420,7 +560,7 @@ def main():
     # multi-CU recurrence (workgroups that wait for each other) is replaced by the single-CU kernels there.
     shared_gpu = world > max(n_dev, 1)
     if shared_gpu:
-        os.environ.setdefault('PSVAE_GRU_MULTI_CU', '0')
+        _lib.set_option('gru_multi_cu', 0)
     dev = torch.device('cuda', local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
     # PSVAE_BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL path on one GPU)
@@ -538,6 +678,7 @@ def main():
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': (mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mp_ms else None},
         'kernel_classes': table,
+        'gru_recurrences_redone': res['gru_recurrences_redone'],
     }
     if 'gine_layer_fused' in classes:
         # aggregation fused into the MLP kernel: reported against max(HBM fraction, MFMA fraction), the HBM numerator
@@ -548,7 +689,8 @@ def main():
         sizes = [b['_native'].sizes for b in leg.batches]
         t_layers = int(model._dims.t_enc)
         H = int(model._dims.hidden)
-        agg_bytes = sum(2 * (2.0 * z['n'] * 4 * H + 4.0 * (z['n'] + 1)) + 5.0 * (z['E'] + z['E_in']) for z in sizes) / len(sizes)
+        # per stack: read x, write agg, hid and y (the training launch saves both intermediates) + CSR
+        agg_bytes = sum(2 * (4.0 * z['n'] * 4 * H + 4.0 * (z['n'] + 1)) + 5.0 * (z['E'] + z['E_in']) for z in sizes) / len(sizes)
         if abs(fcnt / args.profile_steps - t_layers) < 0.5:
             hbm = agg_bytes / (fms / fcnt * 1e-3) / 1e9
             mf = fwork / (fms * 1e-3) / 1e12
@@ -564,6 +706,9 @@ def main():
         out['strong_scaling'] = strong_leg
     if single and not args.no_bulk:
         out['message_passing']['bulk'] = bulk_message_passing(dev)
+    if single and not args.no_configs:
+        out['encode_bulk'] = encode_bulk(dev)
+        out['stress'] = stress_config(dev)
     if single and not args.no_cpu_baseline:
         host_times = {}
         make_batches(tok, args.vocab, args.shape, per_gpu, 2, seed=2021, host_times=host_times)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 4
+#define PSVAE_ABI_VERSION 5
 
 enum {
     PSVAE_OK = 0,
@@ -52,6 +52,31 @@ enum {
 
 const char* psvae_strerror(int code);
 int psvae_abi_version(void);
+
+/* ---- kernel-selection options (no counterpart in the reference) -------------
+ * Where the library chooses between two forms of a kernel by problem size, the choice can be forced: value -1 =
+ * the library's own choice (the default), otherwise as listed.  An option is read on every call, so it can be
+ * changed between calls of one process (the tests run the same step under every setting); at load time each
+ * option takes the value of the environment variable PSVAE_<NAME IN CAPITALS> if that is set.  Results under any
+ * setting satisfy the same parity bounds; with the same setting two runs are bitwise identical.
+ *   streams        0: the step's independent branches stay on the caller's stream (no internal side streams)
+ *   fused_layer    0: a GINE application runs as aggregation + two GEMM launches instead of one fused launch
+ *   fused_bwd      0 / 1: backward of the GINE MLPs as two GEMMs / as one launch
+ *   fused_scorer   0: link scorer as gather + GEMM chain; 1: one launch, forward and backward; 2: forward only
+ *   split_bf16     0: the fused kernels' products on the fp32 matrix instruction instead of the bf16 instruction
+ *                  over operands cut into three bf16 pieces
+ *   split_rows     32 / 64: nodes per workgroup of the cut-operand GINE kernels
+ *   split_gemm     0 / 1: 64-tile weight gradients on the fp32 / on the cut-operand kernel
+ *   wide_gemm      0 / 1: the 160-tile weight-gradient kernel never / wherever the reduction is long enough
+ *   gru_multi_cu   0 / 1: single-CU / multi-CU recurrence
+ *   gru_tiles      1 / 2 / 4: sequence tiles a workgroup of the multi-CU recurrence steps together
+ *   gru_spin_ticks bound of a wait inside the multi-CU recurrence in ticks of 10 ns (default 2 s); 0: give up at
+ *                  once, which exercises the redo on the single-CU kernels
+ * psvae_option_set / _get return PSVAE_E_SHAPE for an unknown name; psvae_option_name(i) enumerates the names
+ * (NULL past the last). */
+int psvae_option_set(const char* name, int value);
+int psvae_option_get(const char* name, int* value);
+const char* psvae_option_name(int index);
 
 /* ---- model sizes (src/utils/nn_utils.py:180-206, src/train.py:92-110) ---- */
 typedef struct psvae_dims {
@@ -135,10 +160,13 @@ typedef struct psvae_batch {
     const float *conds;          /* [B, G] or NULL */
     float *d_conds;              /* [B, G], backward output in decoder-only mode */
     const float *d_z;            /* [B, Z] or NULL */
-    /* Optional status words (device, 8 x int32, caller-zeroed; NULL = not reported).  Word 0 is set to 1 when a
-     * workgroup of the multi-CU GRU recurrence stopped waiting for its partners (its waits are bounded at 2 s so
-     * that a GPU which cannot keep the group resident cannot hang the process): that step's outputs are invalid.
-     * The library only ever sets it, so one buffer passed to every step accumulates over a whole run. */
+    /* Optional status words (device, 8 x int32, caller-zeroed; NULL = not reported).  Word 1 counts the recurrences
+     * (forward or backward) that were redone on the single-CU kernels because a workgroup of the multi-CU GRU
+     * recurrence stopped waiting for its partners (its waits are bounded at 2 s so that a GPU which cannot keep the
+     * group resident cannot hang the process; the redo is queued behind every multi-CU launch and does nothing
+     * otherwise): the step's outputs are valid either way, a non-zero count says that the step took seconds.
+     * Word 0 is reserved for "outputs invalid" and is not set by any kernel of this version.  The library only
+     * ever adds to the words, so one buffer passed to every step accumulates over a whole run. */
     int32_t *status;
 } psvae_batch;
 
@@ -154,7 +182,7 @@ typedef struct psvae_batch {
  *   upstream gradients of those six outputs as DEVICE floats; pass the same
  *   loss_weights.  Gradients are written (not accumulated) into `grads`.
  *   Independent branches of the step run on two internal side streams that fork
- *   from and join back into `stream` inside each call (PSVAE_STREAMS=0 disables).  The two unused parameters of the
+ *   from and join back into `stream` inside each call (option streams = 0 disables).  The two unused parameters of the
  *   decoder-side encoder (its `linear`) have no field and get no gradient.
  * The workspace holds the saved activations: pass the same buffer, dims and
  * batch to forward and backward. */
@@ -201,7 +229,7 @@ int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const p
  * onto a small number of hardware queues in creation order and streams that share a queue serialise, so a process
  * that also creates communicator (RCCL) or other library streams should call this once per device; otherwise
  * optional (the first step call creates the side streams without the check).  Synchronises `stream`.  Returns 0
- * also when the side streams are disabled (PSVAE_STREAMS=0) or already exist. */
+ * also when the side streams are disabled (option streams = 0) or already exist. */
 int psvae_streams_init(void* stream);
 /* Offsets (in floats) of named activations inside the workspace, for tests and
  * the module-level API.  Returns -1 for an unknown name. */
@@ -317,21 +345,29 @@ int psvae_gine_aggregate_forward(const float* x, int ldx, const int32_t* rowptr,
  * for the matrix cores' operand fragments (the whole-step entry points do that once per step).
  * Arithmetic: fp32 in, fp32 out, fp32 accumulation.  The two products run on the bf16 matrix instruction over
  * operands cut exactly into three bf16 pieces each (x = h + m + l), six piece products per product; the result is
- * at least as close to the exact one as a chain of fp32 multiply-adds (the environment switch PSVAE_SPLIT_BF16=0
- * selects the fp32 matrix instruction instead). */
+ * at least as close to the exact one as a chain of fp32 multiply-adds (option split_bf16 = 0 selects the fp32
+ * matrix instruction instead). */
 size_t psvae_gine_layer_scratch_bytes(int H);
 int psvae_gine_layer_forward(const float* x, int ldx, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
                              const float* edge_w, const float* edge_b, float one_plus_eps, const float* w1,
                              const float* b1, const float* w2, const float* b2, float* agg, float* hid, float* y,
                              int ldy, int n, int H, void* scratch, size_t scratch_bytes, void* stream);
+/* Backward of the two Linear layers of that GINE application (what autograd derives from the MLP of
+ * src/modules/common_nn.py:8-23 as used at src/modules/encoder.py:48,58) in ONE launch, given g = dL/dy [n,H] and
+ * the saved hid [n,H]:   d_hid = (g w2) * [hid > 0];   d_agg = d_hid w1      (all matrices contiguous, pitch H).
+ * d_hid is the operand of the first layer's weight gradient (psvae_linear_backward_weight(d_hid, agg)), d_agg the
+ * input of psvae_gine_aggregate_backward.  Same sizes, scratch and arithmetic as the forward entry point. */
+int psvae_gine_layer_backward(const float* g, const float* hid, const float* w1, const float* w2, float* d_hid,
+                              float* d_agg, int n, int H, void* scratch, size_t scratch_bytes, void* stream);
 /* The link scorer's forward pass (src/modules/vae_piece_decoder.py:97-117) in ONE launch: for each of the S selected
  * pairs, pair_in = [emb[src] | emb[dst] | z[graph]] (P = 2H + Z columns), h1 = relu(pair_in w0^T + b0),
  * h2 = relu(h1 w1^T + b1), h3 = h2 w2^T + b2 (the MLP(P, P/2, P, ReLU, 3) of :36-45), logits = h3 w3^T + b3 (4 bond
  * classes), lse = logsumexp(logits), row_loss = lse - logits[gold] (the rows of the edge cross-entropy, :53,117).
  * The pair rows are gathered straight into LDS and the activations stay there between the layers; pair_in [S,P],
  * h1/h2 [S,P/2], h3 [S,P], logits [S,4], row_loss/lse [S] receive the copies a backward pass reads.  Supported for
- * 320 < P/2 <= 384 (H = 300, Z = 56 gives 328), H % 4 == Z % 4 == lde % 4 == 0; scratch: psvae_scorer_scratch_bytes
- * (0 = unsupported size) bytes, 16-byte aligned, for the re-laid weights. */
+ * 320 < P/2 <= 352 (H = 300, Z = 56 gives 328; up to 384 with option split_bf16 = 0: what fits the LDS), H % 4 ==
+ * Z % 4 == lde % 4 == 0 and P % 8 == 0; scratch: psvae_scorer_scratch_bytes (0 = unsupported size) bytes, 16-byte
+ * aligned, for the re-laid weights.  The whole-step entry points run other sizes as gather + GEMM chain. */
 size_t psvae_scorer_scratch_bytes(int H, int Z);
 int psvae_scorer_forward(const float* emb, int lde, const float* z, const int32_t* pair_src, const int32_t* pair_dst,
                          const int32_t* pair_graph, const int32_t* pair_gold, const float* w0, const float* b0,
@@ -339,6 +375,14 @@ int psvae_scorer_forward(const float* emb, int lde, const float* z, const int32_
                          const float* b3, float* pair_in, float* h1, float* h2, float* h3, float* logits,
                          float* row_loss, float* lse, int S, int H, int Z, void* scratch, size_t scratch_bytes,
                          void* stream);
+/* Backward of the scorer's three-layer MLP (src/modules/vae_piece_decoder.py:36-45 applied at :110) in ONE launch,
+ * given d_h3 = dL/dh3 [S,P] and the saved h2, h1 [S,P/2]:
+ *   d_h2 = (d_h3 w2) * [h2 > 0];   d_h1 = (d_h2 w1) * [h1 > 0];   d_pair_in = d_h1 w0        (contiguous rows)
+ * d_h2 / d_h1 are the operands of the weight gradients, d_pair_in [S,P] is what gets scattered back to the atoms
+ * and the latent.  Sizes, scratch and arithmetic as psvae_scorer_forward. */
+int psvae_scorer_backward(const float* d_h3, const float* h2, const float* h1, const float* w0, const float* w1,
+                          const float* w2, float* d_h2, float* d_h1, float* d_pair_in, int S, int H, int Z,
+                          void* scratch, size_t scratch_bytes, void* stream);
 /* dx[j] = (1+eps) da[j] + sum_{e in rowT j} da[colT[e]] * (x[j] + edge(etypeT[e]) > 0)  (+ pooled-gradient broadcast).
  * The same products summed per bond type are the gradient of edge_trans: when d_edge_w [H,4] is given the call
  * also writes it and d_edge_b [H], using `partial`, scratch of psvae_gine_edge_grad_scratch(n, H) floats. */

@@ -323,9 +323,11 @@ class Trainer:
         return float(total.detach()), {k: float(v.detach()) for k, v in losses.items()}
 
 
-def direct_optimize(p, d, z, target, lr, max_iter, patience, selected=(0, 2)):
+def direct_optimize(p, d, z, target, lr, max_iter, patience, selected=(0, 2), keep=None):
     """`direct_optimize` (`src/generate.py:67-89`) with `get_loss` (`:30-44`) and the padding of
-    `predict_props` (`ps_vae_model.py:146-153`) for ONE latent vector `z` [latent]."""
+    `predict_props` (`ps_vae_model.py:146-153`) for ONE latent vector `z` [latent].  `keep` (a list) receives
+    the loss of every step.  Parity status: PINNED by `tests/golden/latent_opt.pt` (the reference's own
+    `generate.direct_optimize`: per-step losses and the returned z for nine runs)."""
     def predict_props(zz):
         q = torch.relu(F.linear(zz, p['predictor.mlp.0.weight'], p['predictor.mlp.0.bias']))
         q = torch.relu(F.linear(q, p['predictor.mlp.2.weight'], p['predictor.mlp.2.bias']))
@@ -352,6 +354,8 @@ def direct_optimize(p, d, z, target, lr, max_iter, patience, selected=(0, 2)):
         opt.step()
         steps += 1
         loss = loss.item()
+        if keep is not None:
+            keep.append(loss)
         if loss < best_loss:
             best_loss, not_inc, best_z = loss, 0, optimized.clone()
         else:
@@ -361,13 +365,15 @@ def direct_optimize(p, d, z, target, lr, max_iter, patience, selected=(0, 2)):
     return best_z.detach(), best_loss, steps
 
 
-def sample_pieces(p, d, z, piece_atoms, max_atom_num, temperature, uniforms):
+def sample_pieces(p, d, z, piece_atoms, max_atom_num, temperature, uniforms, keep=None):
     """The piece-sampling loop of `VAEPieceDecoder.inference` (`src/modules/vae_piece_decoder.py:134-158`)
     for ONE latent `z` [latent].  `torch.multinomial` (:149) is replaced by inversion of the cumulative
     distribution at `uniforms[step]` (its own random stream is not reproducible outside torch);
-    everything else follows the loop line by line.  Parity of this loop is unpinned: the reference's
-    `inference` imports RDKit and cannot run here; the GRU cell and `to_vocab` it uses are the ones the
-    golden fixtures pin through the training step."""
+    everything else follows the loop line by line.  `keep` (a list) receives every step's probability
+    vector.  Parity status: PINNED by `tests/golden/inference.pt`, which holds what the reference's own
+    `inference` computed (probabilities handed to `torch.multinomial` at every step, the pieces drawn from
+    them by the same inversion rule) with RDKit's molecule bookkeeping replaced by recording stand-ins
+    (`tools/make_fixtures.py`)."""
     pad_idx, end_idx = d['num_piece'] - 2, d['num_piece'] - 1
     emb = p['decoder.piece_embedding.weight']
     cur = emb[end_idx].view(1, 1, -1)
@@ -380,6 +386,8 @@ def sample_pieces(p, d, z, piece_atoms, max_atom_num, temperature, uniforms):
         if len(piece_ids) == 0:
             output[end_idx] = float('-inf')
         probs = torch.softmax(output / temperature, dim=-1)
+        if keep is not None:
+            keep.append(probs.detach().clone())
         cdf = torch.cumsum(probs.double(), dim=0)
         target = float(uniforms[len(piece_ids)]) * float(cdf[-1])
         cur_id = int(torch.searchsorted(cdf, torch.tensor(target, dtype=torch.double), right=True))
@@ -398,7 +406,8 @@ def score_links(p, d, z, x, x_pieces, x_pos, edge_index, edge_attr, groups):
     """The link-scoring part of `VAEPieceDecoder.inference` (`src/modules/vae_piece_decoder.py:203-238`) for
     ONE set of fragments: `edge_index` [[a, b], ...] holds the in-piece bonds in both directions in the
     order the loop appends them (:189-196), `edge_attr` their bond types.  Returns
-    (pred_edge_index [E,2], softmax(pred_edge) [E,4])."""
+    (pred_edge_index [E,2], softmax(pred_edge) [E,4]).  Parity status: PINNED by `tests/golden/inference.pt`
+    (the reference's own scorer output for the fragment sets its sampling loop produced)."""
     z = z.view(1, -1)
     node_x = torch.cat([p['decoder.atom_embedding.weight'][torch.tensor(x, dtype=torch.long)],
                         p['decoder.piece_embedding.weight'][torch.tensor(x_pieces, dtype=torch.long)],

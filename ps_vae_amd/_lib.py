@@ -106,6 +106,10 @@ def lib():
     L.psvae_strerror.restype = C.c_char_p
     L.psvae_strerror.argtypes = [C.c_int]
     L.psvae_abi_version.restype = C.c_int
+    L.psvae_option_set.argtypes = [C.c_char_p, C.c_int]
+    L.psvae_option_get.argtypes = [C.c_char_p, P(C.c_int)]
+    L.psvae_option_name.restype = C.c_char_p
+    L.psvae_option_name.argtypes = [C.c_int]
     L.psvae_workspace_bytes.restype = sz
     L.psvae_workspace_bytes.argtypes = [P(Dims), P(Batch)]
     L.psvae_workspace_offset.restype = i64
@@ -137,6 +141,8 @@ def lib():
     L.psvae_gine_layer_scratch_bytes.restype = sz
     L.psvae_gine_layer_scratch_bytes.argtypes = [C.c_int]
     L.psvae_gine_layer_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, vp]
+    L.psvae_gine_layer_backward.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, sz, vp]
+    L.psvae_scorer_backward.argtypes = [vp] * 9 + [C.c_int] * 3 + [vp, sz, vp]
     L.psvae_scorer_scratch_bytes.restype = sz
     L.psvae_scorer_scratch_bytes.argtypes = [C.c_int, C.c_int]
     L.psvae_scorer_forward.argtypes = [vp, C.c_int] + [vp] * 20 + [C.c_int] * 3 + [vp, sz, vp]
@@ -171,14 +177,15 @@ def lib():
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
     L.psvae_profile_event_overhead_ms.restype = C.c_double
     L.psvae_profile_event_overhead_ms.argtypes = [vp]
-    if L.psvae_abi_version() != 4:
+    if L.psvae_abi_version() != 5:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
     return L
 
 
 EXPORTS = (
-    'psvae_strerror', 'psvae_abi_version', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward', 'psvae_train_step',
+    'psvae_strerror', 'psvae_abi_version', 'psvae_option_set', 'psvae_option_get', 'psvae_option_name',
+    'psvae_gine_layer_backward', 'psvae_scorer_backward', 'psvae_workspace_bytes', 'psvae_workspace_offset', 'psvae_step_forward', 'psvae_train_step',
     'psvae_step_backward', 'psvae_step_backward_signal', 'psvae_streams_init', 'psvae_encode', 'psvae_sample_pieces_workspace_bytes', 'psvae_sample_pieces',
     'psvae_score_links', 'psvae_normal_rows', 'psvae_adam_partials', 'psvae_clip_adam', 'psvae_linear_scratch_bytes',
     'psvae_linear_forward', 'psvae_linear_backward_input', 'psvae_linear_backward_weight',
@@ -199,6 +206,26 @@ def profile_collect():
     ms, work, cnt = np.zeros(k), np.zeros(k), np.zeros(k, dtype=np.int64)
     check(L.psvae_profile_collect(ms.ctypes.data, work.ctypes.data, cnt.ctypes.data), 'psvae_profile_collect')
     return {L.psvae_profile_class_name(i).decode(): (float(ms[i]), float(work[i]), int(cnt[i])) for i in range(k) if cnt[i]}
+
+
+def set_option(name, value):
+    """Force a kernel-selection option (`include/psvae.h`: psvae_option_set); -1 gives the choice back to the library.
+    Returns the previous value."""
+    L = lib()
+    old = C.c_int(0)
+    check(L.psvae_option_get(name.encode(), C.byref(old)), f'psvae_option_get({name})')
+    check(L.psvae_option_set(name.encode(), int(value)), f'psvae_option_set({name})')
+    return old.value
+
+
+def option_names():
+    L, out, i = lib(), [], 0
+    while True:
+        n = L.psvae_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
 
 
 def check(rc, what='psvae call'):

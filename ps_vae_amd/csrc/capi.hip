@@ -1,6 +1,10 @@
 // extern "C" surface for the single operators (thin argument checks around the
 // same launchers the whole-step entry points use).
 #include "psvae_internal.h"
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
 
 extern "C" const char* psvae_strerror(int code) {
     switch (code) {
@@ -18,6 +22,54 @@ extern "C" const char* psvae_strerror(int code) {
 }
 
 extern "C" int psvae_abi_version(void) { return PSVAE_ABI_VERSION; }
+
+// ---- kernel-selection options: one table, filled from the environment (PSVAE_<NAME>) the first time it is read
+namespace {
+const char* const option_names[OPT_COUNT] = {"streams", "fused_layer", "fused_bwd", "fused_scorer", "split_bf16", "split_rows",
+                                             "split_gemm", "wide_gemm", "gru_multi_cu", "gru_tiles", "gru_spin_ticks"};
+int option_values[OPT_COUNT];
+std::once_flag option_once;
+
+void options_from_env() {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        char var[64] = "PSVAE_";
+        size_t k = strlen(var);
+        for (const char* c = option_names[i]; *c && k + 1 < sizeof(var); ++c) var[k++] = (char)toupper((unsigned char)*c);
+        var[k] = 0;
+        const char* e = getenv(var);
+        option_values[i] = (e && *e) ? atoi(e) : -1;
+    }
+}
+int option_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, option_names[i]) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+int opt(int which) {
+    std::call_once(option_once, options_from_env);
+    return option_values[which];
+}
+
+extern "C" int psvae_option_set(const char* name, int value) {
+    const int i = option_index(name);
+    if (i < 0) return PSVAE_E_SHAPE;
+    std::call_once(option_once, options_from_env);
+    option_values[i] = value < 0 ? -1 : value;
+    return 0;
+}
+
+extern "C" int psvae_option_get(const char* name, int* value) {
+    const int i = option_index(name);
+    if (i < 0) return PSVAE_E_SHAPE;
+    if (!value) return PSVAE_E_NULL;
+    *value = opt(i);
+    return 0;
+}
+
+extern "C" const char* psvae_option_name(int index) { return index >= 0 && index < OPT_COUNT ? option_names[index] : nullptr; }
 
 extern "C" int psvae_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
                                float* partials, float max_norm, float lr, float beta1, float beta2, float adam_eps,
@@ -88,6 +140,21 @@ extern "C" int psvae_gine_layer_forward(const float* x, int ldx, const int32_t* 
     return gine_layer_fwd((hipStream_t)stream, &g, 1, ldx, ldy, n, H, agg != nullptr);
 }
 
+extern "C" int psvae_gine_layer_backward(const float* g, const float* hid, const float* w1, const float* w2, float* d_hid,
+                                         float* d_agg, int n, int H, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!g || !hid || !w1 || !w2 || !d_hid || !d_agg || !scratch) return PSVAE_E_NULL;
+    if (n < 0 || H < 4) return PSVAE_E_SHAPE;
+    if (!gine_layer_fused_supported(H, H, H)) return PSVAE_E_SHAPE;
+    if (!aligned16(scratch)) return PSVAE_E_ALIGN;
+    if (scratch_bytes < psvae_gine_layer_scratch_bytes(H)) return PSVAE_E_WORKSPACE;
+    float* w1tp = (float*)scratch;
+    float* w2tp = w1tp + fused_pack_floats(H, H);
+    const FusedPack pk[2] = {{w1, w1tp, H, H, H, true, gine_layer_split(H)}, {w2, w2tp, H, H, H, true, gine_layer_split(H)}};
+    PSVAE_TRY(fused_pack((hipStream_t)stream, pk, 2));
+    FusedLayerBwdGroup grp{g, hid, w2tp, w1tp, d_hid, d_agg};
+    return gine_layer_bwd((hipStream_t)stream, &grp, 1, n, H);
+}
+
 extern "C" size_t psvae_scorer_scratch_bytes(int H, int Z) {
     if (!scorer_fused_supported(H, Z, H)) return 0;
     return scorer_pack_floats(H, Z) * sizeof(float);
@@ -108,6 +175,19 @@ extern "C" int psvae_scorer_forward(const float* emb, int lde, const float* z, c
     ScorerFwd f{emb, lde, z, pair_src, pair_dst, pair_graph, pair_gold, (const float*)scratch, b0, b1, b2, w3, b3,
                 pair_in, h1, h2, h3, logits, row_loss, lse, S, H, Z};
     return scorer_fwd_fused((hipStream_t)stream, f);
+}
+
+extern "C" int psvae_scorer_backward(const float* d_h3, const float* h2, const float* h1, const float* w0, const float* w1,
+                                     const float* w2, float* d_h2, float* d_h1, float* d_pair_in, int S, int H, int Z,
+                                     void* scratch, size_t scratch_bytes, void* stream) {
+    if (!w0 || !w1 || !w2 || !scratch) return PSVAE_E_NULL;
+    if (S < 0) return PSVAE_E_SHAPE;
+    if (!scorer_fused_supported(H, Z, H)) return PSVAE_E_SHAPE;
+    if (!aligned16(scratch)) return PSVAE_E_ALIGN;
+    if (scratch_bytes < psvae_scorer_scratch_bytes(H, Z)) return PSVAE_E_WORKSPACE;
+    PSVAE_TRY(scorer_pack_bwd((hipStream_t)stream, w0, w1, w2, (float*)scratch, H, Z));
+    ScorerBwd b{d_h3, h2, h1, (const float*)scratch, d_h2, d_h1, d_pair_in, S, H, Z};
+    return scorer_bwd_fused((hipStream_t)stream, b);
 }
 
 extern "C" size_t psvae_gine_edge_grad_scratch(int n, int H) {

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_kernel(const FLBArg
 //     pin  = [emb[src] | emb[dst] | z[graph]]                        pair input, gathered straight into LDS
 //     s1   = relu(pin W0^T + b0);  s2 = relu(s1 W1^T + b1);  s3 = s2 W2^T + b2      MLP(P, P/2, P, ReLU, 3)
 //     logits = s3 W3^T + b3  (4 bond classes), lse, row loss = lse - logits[gold]   Linear + cross-entropy rows
-// A workgroup owns 16 consecutive pairs; the activations move between two LDS images and are copied to memory
+// A workgroup owns 16 RT consecutive pairs; the activations move between two LDS images and are copied to memory
 // only for backward's use.  The last MLP layer (P outputs) runs as two halves of P/2 columns over the same image.
 struct ScorerArgs {
     const float* emb; int lde;                 // decoder-side node embeddings [n, lde]
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_fwd_kernel(const ScorerArgs
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of the link scorer's MLP as ONE launch (the head's backward has already turned the logits' gradient
 // into ds3 = dL/ds3):   ds2 = (ds3 W2) * [s2 > 0];   ds1 = (ds2 W1) * [s1 > 0];   dpin = ds1 W0.
-// 16 pairs per workgroup; ds2 / ds1 (operands of the weight gradients) and dpin (scattered to the atoms afterwards)
+// 16 RT pairs per workgroup; ds2 / ds1 (operands of the weight gradients) and dpin (scattered to the atoms afterwards)
 // go to memory.  The weights arrive packed in their transposed role, W0 as two halves of P/2 output columns.
 struct ScorerBwdArgs {
     const float *ds3, *s2, *s1;
@@ -1299,9 +1299,9 @@ static int fused_ct(int N) {          // the kernels' template value for N outpu
 }
 
 // Nodes per workgroup of the cut-operand kernels: 64 once that still leaves every compute unit a round and a half
-// of workgroups (and the three planes of 64 rows fit the LDS), 32 below.  PSVAE_SPLIT_ROWS=32/64 forces.
+// of workgroups (and the three planes of 64 rows fit the LDS), 32 below.  Option split_rows = 32 / 64 forces.
 static int split_rows(int n, int ng, int H, size_t extra_lds) {
-    static const int forced = [] { const char* e = getenv("PSVAE_SPLIT_ROWS"); return e ? atoi(e) : 0; }();
+    const int forced = opt(OPT_SPLIT_ROWS);
     const bool fits = (size_t)3 * 64 * flb_pitch_bytes(H) + extra_lds <= 156 * 1024;
     if (forced == 32 || !fits) return 32;
     if (forced == 64) return 64;
@@ -1323,11 +1323,10 @@ size_t fused_pack_floats(int N, int K) {
 }
 
 // Do the fused GINE kernels run their products on the bf16 matrix instruction over three-way cut operands (fp32
-// accuracy, see above)?  PSVAE_SPLIT_BF16=0 keeps the fp32 instruction.  Whoever packs the weights for
+// accuracy, see above)?  Option split_bf16 = 0 keeps the fp32 instruction.  Whoever packs the weights for
 // gine_layer_fwd / gine_layer_bwd must ask this and set FusedPack::split accordingly.
 bool gine_layer_split(int H) {
-    static const bool off = [] { const char* e = getenv("PSVAE_SPLIT_BF16"); return e && e[0] == '0'; }();
-    return !off && H >= 16 && H <= 512;
+    return opt(OPT_SPLIT_BF16) != 0 && H >= 16 && H <= 512;
 }
 
 int fused_pack(hipStream_t s, const FusedPack* d, int count) {
@@ -1432,9 +1431,37 @@ int gine_layer_fwd(hipStream_t s, const FusedLayerGroup* grp, int ng, int ldx, i
     return 0;
 }
 
+// LDS the one-launch scorer kernels need for 32 pairs per workgroup, in the form the products currently take
+// (cut operands: three bf16 planes per image, regions reused as their contents die; fp32: two images side by side),
+// and the most a workgroup may ask for.  One place, so that the predicate, the launchers and the size queries agree.
+struct ScorerLds { size_t fwd, bwd, cap; int PA, PB, P3; size_t off2_fwd, off2_bwd; };
+static ScorerLds scorer_lds(int H, int Z) {
+    const int P = 2 * H + Z, P2 = P / 2;
+    ScorerLds l{};
+    if (gine_layer_split(H)) {
+        l.PA = flb_pitch_bytes(P); l.PB = flb_pitch_bytes(P2); l.P3 = P + 4;
+        const size_t planes2 = (size_t)3 * 32 * l.PB;
+        l.off2_fwd = (std::max(planes2, (size_t)32 * l.P3 * sizeof(float)) + 255) / 256 * 256;
+        l.off2_bwd = (planes2 + 255) / 256 * 256;
+        l.fwd = std::max((size_t)3 * 32 * l.PA, l.off2_fwd + planes2);
+        l.bwd = std::max((size_t)3 * 32 * l.PA, l.off2_bwd + planes2);
+        l.cap = 159 * 1024;
+    } else {
+        l.PA = fl_pitch(P); l.PB = fl_pitch(P2);
+        l.fwd = l.bwd = (size_t)32 * (l.PA + l.PB) * sizeof(float);
+        l.cap = 156 * 1024;
+    }
+    return l;
+}
+
+// Sizes the one-launch scorer kernels take: the template instance covers 320 < P/2 <= 384 output columns, and both
+// directions' images must fit the LDS (with cut operands that ends at P/2 = 352; H = 300, Z = 56 gives 328).
+// Everything else runs as pair gather + GEMM chain + head.
 bool scorer_fused_supported(int H, int Z, int lde) {
     const int P = 2 * H + Z;
-    return H % 4 == 0 && Z % 4 == 0 && lde % 4 == 0 && P % 8 == 0 && P / 2 > 320 && P / 2 <= 384;
+    if (!(H % 4 == 0 && Z % 4 == 0 && lde % 4 == 0 && P % 8 == 0 && P / 2 > 320 && P / 2 <= 384)) return false;
+    const ScorerLds l = scorer_lds(H, Z);
+    return l.fwd <= l.cap && l.bwd <= l.cap;
 }
 
 // packed-weight floats the fused scorer needs (w0, w1, two halves of w2), in that order
@@ -1469,15 +1496,13 @@ int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
     a.w2p_hi = a.w2p_lo + fused_pack_floats(P2, P2);
     a.b0 = f.b0; a.b1 = f.b1; a.b2 = f.b2; a.w3 = f.w3; a.b3 = f.b3;
     a.pin = f.pin; a.s1 = f.s1; a.s2 = f.s2; a.s3 = f.s3; a.logits = f.logits; a.row_loss = f.row_loss; a.lse = f.lse;
-    a.S = f.S; a.H = f.H; a.Z = f.Z; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
+    const ScorerLds sl = scorer_lds(f.H, f.Z);
+    a.S = f.S; a.H = f.H; a.Z = f.Z; a.P = P; a.P2 = P2; a.PA = sl.PA; a.PB = sl.PB;
     // 32 pairs per workgroup (141 KB of LDS, one workgroup per CU): a streamed weight block then feeds twice the
-    // MFMAs of the 16-pair form (PSVAE_SCORER_ROWS=16 selects that one)
-    static const int rows = [] { const char* e = getenv("PSVAE_SCORER_ROWS"); return e && atoi(e) == 16 ? 16 : 32; }();
+    // matrix instructions of a 16-pair form (measured: 16 pairs ran slower than the GEMM chain everywhere)
     if (gine_layer_split(f.H)) {        // products on the bf16 matrix instruction over cut operands (weights packed to match)
-        a.PA = flb_pitch_bytes(P); a.PB = flb_pitch_bytes(P2);
-        const int P3 = P + 4;
-        const size_t planes2 = (size_t)3 * 32 * a.PB, off2 = (std::max(planes2, (size_t)32 * P3 * sizeof(float)) + 255) / 256 * 256;
-        const size_t lds = std::max((size_t)3 * 32 * a.PA, off2 + planes2);
+        const int P3 = sl.P3;
+        const size_t off2 = sl.off2_fwd, lds = sl.fwd;
         static bool split_attr_set = false;
         if (!split_attr_set) {
             if (hipFuncSetAttribute((const void*)scorer_fwd_split_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
@@ -1490,18 +1515,16 @@ int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
         PSVAE_LAUNCH_CHECK();
         return 0;
     }
-    const size_t lds = (size_t)rows * (a.PA + a.PB) * sizeof(float);
+    const size_t lds = sl.fwd;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)scorer_fwd_kernel<6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)scorer_fwd_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scorer_fwd_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_set = true;
     }
     if (lds > 156 * 1024) return PSVAE_E_SHAPE;
     ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P + 4.0 * P));
-    if (rows == 16) hipLaunchKernelGGL((scorer_fwd_kernel<6, 1>), dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((scorer_fwd_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a);
+    hipLaunchKernelGGL((scorer_fwd_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -1580,12 +1603,10 @@ int scorer_bwd_fused(hipStream_t s, const ScorerBwd& f) {
     a.w2tp = f.packed; a.w1tp = a.w2tp + fused_pack_floats(P2, P); a.w0tp_lo = a.w1tp + fused_pack_floats(P2, P2);
     a.w0tp_hi = a.w0tp_lo + fused_pack_floats(P2, P2);
     a.ds2 = f.ds2; a.ds1 = f.ds1; a.dpin = f.dpin;
-    a.S = f.S; a.P = P; a.P2 = P2; a.PA = fl_pitch(P); a.PB = fl_pitch(P2);
-    static const int rows = [] { const char* e = getenv("PSVAE_SCORER_ROWS"); return e && atoi(e) == 16 ? 16 : 32; }();
+    const ScorerLds sl = scorer_lds(f.H, f.Z);
+    a.S = f.S; a.P = P; a.P2 = P2; a.PA = sl.PA; a.PB = sl.PB;
     if (gine_layer_split(f.H)) {
-        a.PA = flb_pitch_bytes(P); a.PB = flb_pitch_bytes(P2);
-        const size_t planes2 = (size_t)3 * 32 * a.PB, off2 = (planes2 + 255) / 256 * 256;
-        const size_t lds = std::max((size_t)3 * 32 * a.PA, off2 + planes2);
+        const size_t off2 = sl.off2_bwd, lds = sl.bwd;
         static bool split_attr_set = false;
         if (!split_attr_set) {
             if (hipFuncSetAttribute((const void*)scorer_bwd_split_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
@@ -1598,18 +1619,16 @@ int scorer_bwd_fused(hipStream_t s, const ScorerBwd& f) {
         PSVAE_LAUNCH_CHECK();
         return 0;
     }
-    const size_t lds = (size_t)rows * (a.PA + a.PB) * sizeof(float);
+    const size_t lds = sl.bwd;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)scorer_bwd_kernel<6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)scorer_bwd_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scorer_bwd_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_set = true;
     }
     if (lds > 156 * 1024) return PSVAE_E_SHAPE;
     ProfScope prof(s, KC_SCORER, 2.0 * f.S * ((double)P * P2 + (double)P2 * P2 + (double)P2 * P));
-    if (rows == 16) hipLaunchKernelGGL((scorer_bwd_kernel<6, 1>), dim3((f.S + 15) / 16), dim3(FL_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((scorer_bwd_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a);
+    hipLaunchKernelGGL((scorer_bwd_kernel<6, 2>), dim3((f.S + 31) / 32), dim3(FL_THREADS), lds, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -889,14 +889,13 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const ReduceP p) {
 // CU, all resident at once, each with at least 4 K-steps; these launches run beside other streams' work in the
 // training step.  (While the weight gradients ran on the fp32 kernel - 190 registers, one to two workgroups per CU -
 // 384 was the better target there: 512 cost the step 1.3 %; with the cut-operand kernel, which shares a CU better,
-// 512 gains 0.7 %, 256 and 768 lose as much.)  PSVAE_SPLIT_TARGET overrides.
+// 512 gains 0.7 %, 256 and 768 lose as much.)
 struct Plan { int splits, rchunk; };
 Plan plan_splits(int M, int N, int R, int nseg) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nseg;
     Plan pl{1, (int)round_up(R > 0 ? R : 1, BK)};
     if (tiles >= 200 || R <= 4 * BK) return pl;
-    static const int forced = [] { const char* e = getenv("PSVAE_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
-    const int target = forced > 0 ? forced : 512;
+    const int target = 512;
     int want = (int)(target / tiles);      // rounded down
     int maxs = R / (4 * BK);
     if (want > maxs) want = maxs;
@@ -911,15 +910,12 @@ Plan plan_splits(int M, int N, int R, int nseg) {
 // long enough for every workgroup of the split to run WIDE_MIN_STEPS K-steps.  One workgroup per CU (120 KB of LDS);
 // the split aims at 128 workgroups: in the training step these products run beside two other streams' kernels, which
 // take the other CUs (128 against 256: +2.3 % on the 128-graph step, +1 % at 256 graphs, equal at 1024; alone on the
-// chip 256 is 40 % faster).  PSVAE_WIDE_GEMM=0 / 1 forces the kernel off / on (where the shape allows),
-// PSVAE_WIDE_TARGET the workgroup count, PSVAE_WIDE_PAD_PCT the padding allowed (percent of the 64-tiles').
+// chip 256 is 40 % faster).  Option wide_gemm = 0 / 1 forces the kernel off / on (wherever the reduction is long enough).
 constexpr int WIDE_MIN_STEPS = 4;
 Plan plan_wide(int M, int N, int R, int nseg) {
     Plan none{0, 0};
-    static const int forced = [] { const char* e = getenv("PSVAE_WIDE_GEMM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    static const int target_forced = [] { const char* e = getenv("PSVAE_WIDE_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-    static const int min_steps = [] { const char* e = getenv("PSVAE_WIDE_MIN_STEPS"); return e && atoi(e) > 0 ? atoi(e) : WIDE_MIN_STEPS; }();
-    static const int pad_forced = [] { const char* e = getenv("PSVAE_WIDE_PAD_PCT"); return e && atoi(e) >= 100 ? atoi(e) : 0; }();
+    const int forced = opt(OPT_WIDE_GEMM);
+    constexpr int min_steps = WIDE_MIN_STEPS;
     if (forced == 0) return none;
     const long long tw = (long long)((M + WD_T - 1) / WD_T) * ((N + WD_T - 1) / WD_T), t64 = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     // Padding the 160-tiles may add over the 64-tiles': none for short reductions, 30 % from 12 k rows (node_trans,
@@ -927,11 +923,11 @@ Plan plan_wide(int M, int N, int R, int nseg) {
     // one: the 160-tiles beat it by 1.5 x per padded flop alone and by more beside other kernels (they hold 128 - 192
     // CUs, it floods all of them).  That puts the link scorer's 656 x 329, 328 x 329 and 328 x 657 on them from 768
     // graphs per step (+1 %; +1.7 % at 1024), together with a split for 192 workgroups instead of 128 (+1.5 % more at
-    // 1024).  From 10 k rows on the same rule loses 1 % at 512 graphs.  PSVAE_WIDE_R160 moves the row count.
-    static const int r160 = [] { const char* e = getenv("PSVAE_WIDE_R160"); return e && atoi(e) > 0 ? atoi(e) : 18432; }();
-    const int pad_pct = pad_forced ? pad_forced : (R >= r160 ? 160 : (R >= 12288 ? 130 : 100));
+    // 1024).  From 10 k rows on the same rule loses 1 % at 512 graphs.  (Option wide_gemm = 1 accepts any padding.)
+    constexpr int r160 = 18432;
+    const int pad_pct = forced == 1 ? 1000 : (R >= r160 ? 160 : (R >= 12288 ? 130 : 100));
     if (tw * WD_T * WD_T * 100 > t64 * BM * BN * pad_pct) return none;
-    const int target = target_forced ? target_forced : (R >= r160 ? 192 : 128);
+    const int target = R >= r160 ? 192 : 128;
     const long long tiles = tw * nseg;
     int want = (int)(target / tiles);
     const int maxs = R / (min_steps * BK);
@@ -1013,8 +1009,8 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
         // the time the fp32 kernel needs (97 against 105 TFLOP/s at 95 k rows) but with 128 + 32 registers instead of
         // 190 + 32 it shares a CU better with the other streams' kernels: +2 % on the 128-graph step, +1 % at 256 and
         // 512 graphs, -1.5 % at 1024 (reductions over 19 k - 95 k rows there).  Used for reductions under 18 k rows;
-        // PSVAE_SPLIT_GEMM=0 / 1 forces fp32 / cut operands.
-        static const int split_forced = [] { const char* e = getenv("PSVAE_SPLIT_GEMM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+        // option split_gemm = 0 / 1 forces fp32 / cut operands.
+        const int split_forced = opt(OPT_SPLIT_GEMM);
         const Plan pw = (d.a_t && d.b_t && vec && d.sum_segments) ? plan_wide(d.M, d.N, d.R, d.nseg) : Plan{0, 0};
         if (pw.splits > 0 && d.scratch && d.scratch_floats >= (size_t)d.nseg * pw.splits * d.M * round_up(d.N, 16)) {
             static bool wide_attr_set = false;

@@ -36,8 +36,12 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
                                                        const float* __restrict__ whh, const float* __restrict__ bhh,
                                                        float* __restrict__ hseq, float* __restrict__ hprev,
-                                                       float* __restrict__ gates, int B, int T, int R) {
+                                                       float* __restrict__ gates, int B, int T, int R,
+                                                       const unsigned int* run_if, unsigned int* redo_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // as the redo of a multi-CU recurrence that gave up (run_if = its give-up word): nothing to do unless it did
+    if (run_if && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (redo_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(redo_count, 1u);
     const int R16 = (R + 15) & ~15;
     float* buf0 = smem;
     float* buf1 = smem + R16 * ROWS;
@@ -127,8 +131,11 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dhseq, const float* __restrict__ hprev,
                                                        const float* __restrict__ gates, const float* __restrict__ whh,
                                                        float* __restrict__ dgi, float* __restrict__ dgh,
-                                                       float* __restrict__ dh0, int B, int T, int R) {
+                                                       float* __restrict__ dh0, int B, int T, int R,
+                                                       const unsigned int* run_if, unsigned int* redo_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (run_if && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (redo_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(redo_count, 1u);
     const int R16 = (R + 15) & ~15, G = 3 * R, G16 = (G + 15) & ~15;
     float* sDH = smem;                 // [16][R16] running dL/dh
     float* sG = smem + ROWS * R16;     // tile image of d(gh) [16 x G16]
@@ -205,7 +212,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr unsigned long long SPIN_LIMIT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock
+constexpr unsigned long long SPIN_LIMIT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock (option gru_spin_ticks)
 constexpr int EXCH_HEADER_WORDS = 32;                            // 256 B: word 0 = give-up flag
 
 __device__ __forceinline__ unsigned long long granule(unsigned tag, float v) {
@@ -215,11 +222,17 @@ __device__ __forceinline__ unsigned long long granule(unsigned tag, float v) {
 // One wave re-reads its exchange words until every one carries `tag`: `count` (<= N, wave-uniform, >= 1) words,
 // `stride` words apart, for each of `ntl` (<= RB, wave-uniform, >= 1) sequence tiles that lie `tile_stride` words
 // apart.  All RB * N loads of a round are in flight together (surplus slots repeat the last word / the last tile:
-// no branch around a load).  Gives up (returns false) when another wave has given up or after SPIN_LIMIT_TICKS.
+// no branch around a load).  Gives up (returns false) when another wave has given up or after `limit` ticks of
+// the 100 MHz wall clock (0: at once); the launcher queues the single-CU kernel behind this one, which redoes the
+// whole recurrence when the give-up word is set.
 template <int N, int RB>
 __device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, long long tile_stride, int ntl, unsigned tag,
-                                      float (&v)[RB][N], gu32* giveup, gu32* sticky, int lane) {
+                                      float (&v)[RB][N], gu32* giveup, unsigned long long limit, int lane) {
     const unsigned long long t0 = wall_clock64();
+    if (limit == 0ull) {
+        if (lane == 0) __hip_atomic_store(giveup, 1u, RLX_AGENT);
+        return false;
+    }
     for (unsigned spins = 1;; ++spins) {
         bool ok = true;
 #pragma unroll
@@ -236,11 +249,8 @@ __device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, 
         if (__all(ok)) return true;
         if ((spins & 63u) == 0u) {
             if (__hip_atomic_load(giveup, RLX_AGENT) != 0u) return false;
-            if (wall_clock64() - t0 > SPIN_LIMIT_TICKS) {
-                if (lane == 0) {
-                    __hip_atomic_store(giveup, 1u, RLX_AGENT);
-                    if (sticky) __hip_atomic_store(sticky, 1u, RLX_AGENT);     // outlives the next clearing of the exchange buffer
-                }
+            if (wall_clock64() - t0 > limit) {
+                if (lane == 0) __hip_atomic_store(giveup, 1u, RLX_AGENT);
                 return false;
             }
         }
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
                                                            const float* __restrict__ whh, const float* __restrict__ bhh,
                                                            float* __restrict__ hseq, float* __restrict__ hprev,
                                                            float* __restrict__ gates, unsigned long long* exch_,
-                                                           int B, int T, int R, int n_st, unsigned int* sticky_) {
+                                                           int B, int T, int R, int n_st, unsigned long long spin_limit) {
     __shared__ float red[2][RB][4][3][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,7 +278,6 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
     const int nks = R >> 2;
     const int cnt = nks > wave ? (nks - wave + 3) >> 2 : 0;        // this wave's K-steps: ks = wave + 4 i
     gu32* giveup = (gu32*)exch_;
-    gu32* sticky = (gu32*)sticky_;
     gu64* exch = (gu64*)exch_ + EXCH_HEADER_WORDS;
     const int ucol = min(j0 + j, R - 1);                           // B-operand column (columns >= R are discarded)
     float wr[KSW], wz[KSW], wn[KSW];
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
                     }
             } else if (cnt > 0) {
                 gu64* first = exch + ((long long)((t & 1) * n_st + st0) * R + 4 * wave + kq) * 16 + j;
-                if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)R * 16, ntl, (unsigned)t, a, giveup, sticky, lane)) s_fail = 1;
+                if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)R * 16, ntl, (unsigned)t, a, giveup, spin_limit, lane)) s_fail = 1;
             }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
                                                            const float* __restrict__ gates, const float* __restrict__ whh,
                                                            float* __restrict__ dgi, float* __restrict__ dgh,
                                                            float* __restrict__ dh0, unsigned long long* exch_,
-                                                           int B, int T, int R, int n_st, unsigned int* sticky_) {
+                                                           int B, int T, int R, int n_st, unsigned long long spin_limit) {
     __shared__ float red[2][RB][4][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -386,7 +395,6 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
     const int G = 3 * R, nks = G >> 2;
     const int cnt = nks > wave ? (nks - wave + 3) >> 2 : 0;
     gu32* giveup = (gu32*)exch_;
-    gu32* sticky = (gu32*)sticky_;
     gu64* exch = (gu64*)exch_ + EXCH_HEADER_WORDS;
     const int ucol = min(j0 + j, R - 1);
     float wb[KSW];
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(256) void gru_bwd_coop_kernel(const float* __restri
                 for (int i = 0; i < KSW; ++i) a[rb][i] = 0.f;
             if (cnt > 0) {
                 gu64* first = exch + (long long)((sidx & 1) * n_st + st0) * G * 16 + (long long)(4 * wave + kq) * 16 + j;
-                if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)G * 16, ntl, (unsigned)(sidx + 1), a, giveup, sticky, lane)) s_fail = 1;
+                if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)G * 16, ntl, (unsigned)(sidx + 1), a, giveup, spin_limit, lane)) s_fail = 1;
             }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -492,9 +500,9 @@ int coop_slots(int ntile, int n_groups) {
 // Sequence tiles a workgroup steps together: the smallest of 1, 2, max_rb that brings all tiles of the batch
 // into one round of resident workgroups (a round costs T cross-CU hops whatever a workgroup carries, and the
 // spinning workgroups of every further round hold their CUs against the kernels of the other streams).
-// PSVAE_GRU_TILES=1/2/4 forces.
+// Option gru_tiles = 1 / 2 / 4 forces.
 int coop_tiles_per_group(int ntile, int n_st, int max_rb) {
-    static const int forced = [] { const char* e = getenv("PSVAE_GRU_TILES"); return e ? atoi(e) : 0; }();
+    const int forced = opt(OPT_GRU_TILES);
     if (forced == 1 || forced == 2 || forced == 4) return forced < max_rb ? forced : max_rb;
     int slots = 240 / ntile;
     if (slots < 1) slots = 1;
@@ -517,10 +525,15 @@ size_t gru_exchange_bytes(int B, int T, int R) {
 // the training step, the multi-CU kernels win up to 640 sequences, tie at 768 and lose 5 % at 1024, 6 % at 2048.
 constexpr int COOP_MAX_TILES = 48;
 
+static unsigned long long spin_limit() {
+    const int v = opt(OPT_GRU_SPIN_TICKS);
+    return v < 0 ? SPIN_LIMIT_TICKS : (unsigned long long)v;
+}
+
 static bool coop_ok(int R, const void* exch, size_t exch_bytes, int B, int T) {
-    // PSVAE_GRU_MULTI_CU=0 forces the single-CU kernels (e.g. on a GPU that other processes keep busy: the
-    // multi-CU kernels need all workgroups of a sequence tile resident at the same time), =1 the multi-CU ones
-    static const int forced = [] { const char* e = getenv("PSVAE_GRU_MULTI_CU"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    // option gru_multi_cu = 0 forces the single-CU kernels (e.g. on a GPU that other processes keep busy: the
+    // multi-CU kernels need all workgroups of a sequence tile resident at the same time), 1 the multi-CU ones
+    const int forced = opt(OPT_GRU_MULTI_CU);
     const bool wanted = forced >= 0 ? forced == 1 : (B + ROWS - 1) / ROWS <= COOP_MAX_TILES;
     return wanted && exch && R % 4 == 0 && R >= 16 && R <= 256 && (reinterpret_cast<uintptr_t>(exch) & 15) == 0 &&
            exch_bytes >= gru_exchange_bytes(B, T, R);
@@ -539,7 +552,8 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
     if (B == 0 || T == 0) return 0;
     if (R % 4 || !aligned16(whh)) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, ntiles = R16 / 16;
-    if (coop_ok(R, exch, exch_bytes, B, T)) {
+    const bool coop = coop_ok(R, exch, exch_bytes, B, T);
+    if (coop) {
         const int n_st = (B + ROWS - 1) / ROWS;
         const size_t used = (size_t)EXCH_HEADER_WORDS * 8 + 2 * (size_t)n_st * R * ROWS * 8;
         ProfScope prof(s, KC_GRU_FWD, 2.0 * B * T * 3 * R * R);
@@ -551,19 +565,23 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
         const int rb = coop_tiles_per_group(ntiles, n_st, narrow ? 4 : 2);
         const dim3 grid(ntiles, coop_slots(ntiles, (n_st + rb - 1) / rb));
 #define PSVAE_GRU_FWD(KSW, RB) hipLaunchKernelGGL((gru_fwd_coop_kernel<KSW, RB>), grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, \
-                                                  gates, (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status)
+                                                  gates, (unsigned long long*)exch, B, T, R, n_st, spin_limit())
         if (narrow) { if (rb == 4) PSVAE_GRU_FWD(13, 4); else if (rb == 2) PSVAE_GRU_FWD(13, 2); else PSVAE_GRU_FWD(13, 1); }
         else { if (rb == 2) PSVAE_GRU_FWD(16, 2); else PSVAE_GRU_FWD(16, 1); }
 #undef PSVAE_GRU_FWD
         PSVAE_LAUNCH_CHECK();
-        return 0;
     }
     const size_t lds = (size_t)2 * R16 * ROWS * sizeof(float);
     if (lds > 64 * 1024) return PSVAE_E_SHAPE;
     const int nwaves = ntiles < 16 ? ntiles : 16;
-    ProfScope prof(s, KC_GRU_FWD, 2.0 * B * T * 3 * R * R);
+    // after a multi-CU launch: the same recurrence on the single-CU kernel, whose workgroups leave at once unless a
+    // workgroup of the multi-CU kernel gave up waiting (the give-up word heads the exchange buffer); word 1 of
+    // `status` counts the recurrences redone this way
+    const unsigned int* run_if = coop ? (const unsigned int*)exch : nullptr;
+    unsigned int* redone = coop && status ? (unsigned int*)status + 1 : nullptr;
+    ProfScope prof(s, KC_GRU_FWD, coop ? 0.0 : 2.0 * B * T * 3 * R * R);
     hipLaunchKernelGGL(gru_fwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(64 * nwaves), lds, s, gi, h0, whh, bhh, hseq,
-                       hprev, gates, B, T, R);
+                       hprev, gates, B, T, R, run_if, redone);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -574,7 +592,8 @@ int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* 
     if (B == 0) return 0;
     if (R % 4) return PSVAE_E_ALIGN;
     const int R16 = (R + 15) & ~15, G16 = (3 * R + 15) & ~15, ntiles = R16 / 16;
-    if (T > 0 && coop_ok(R, exch, exch_bytes, B, T)) {
+    const bool coop = T > 0 && coop_ok(R, exch, exch_bytes, B, T);
+    if (coop) {
         const int n_st = (B + ROWS - 1) / ROWS;
         ProfScope prof(s, KC_GRU_BWD, 2.0 * B * T * 3 * R * R);
         if (!exch_clean) {
@@ -585,19 +604,20 @@ int gru_bwd(hipStream_t s, const float* dhseq, const float* hprev, const float* 
         const int rb = coop_tiles_per_group(ntiles, n_st, narrow ? 2 : 1);
         const dim3 grid(ntiles, coop_slots(ntiles, (n_st + rb - 1) / rb));
 #define PSVAE_GRU_BWD(KSW, RB) hipLaunchKernelGGL((gru_bwd_coop_kernel<KSW, RB>), grid, dim3(256), 0, s, dhseq, hprev, gates, whh, dgi, \
-                                                  dgh, dh0, (unsigned long long*)exch, B, T, R, n_st, (unsigned int*)status)
+                                                  dgh, dh0, (unsigned long long*)exch, B, T, R, n_st, spin_limit())
         if (narrow) { if (rb == 2) PSVAE_GRU_BWD(38, 2); else PSVAE_GRU_BWD(38, 1); }
         else PSVAE_GRU_BWD(48, 1);
 #undef PSVAE_GRU_BWD
         PSVAE_LAUNCH_CHECK();
-        return 0;
     }
     const size_t lds = (size_t)(ROWS * R16 + ROWS * G16) * sizeof(float);
     if (lds > 64 * 1024) return PSVAE_E_SHAPE;
     const int nwaves = ntiles < 16 ? ntiles : 16;
-    ProfScope prof(s, KC_GRU_BWD, 2.0 * B * T * 3 * R * R);
+    const unsigned int* run_if = coop ? (const unsigned int*)exch : nullptr;      // the redo, as in gru_fwd
+    unsigned int* redone = coop && status ? (unsigned int*)status + 1 : nullptr;
+    ProfScope prof(s, KC_GRU_BWD, coop ? 0.0 : 2.0 * B * T * 3 * R * R);
     hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(64 * nwaves), lds, s, dhseq, hprev, gates, whh,
-                       dgi, dgh, dh0, B, T, R);
+                       dgi, dgh, dh0, B, T, R, run_if, redone);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

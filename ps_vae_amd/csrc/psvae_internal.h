@@ -19,6 +19,26 @@
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// ---------------------------------------------------------------- kernel-selection options (capi.hip)
+// Every choice between two forms of a kernel that the library makes by size can be forced through
+// psvae_option_set(name, value) (or, at load time, the environment variable PSVAE_<NAME>); -1 = the library's own
+// choice.  Read on every call, so a test can flip them inside one process.
+enum Option {
+    OPT_STREAMS = 0,     // 0: everything on the caller's stream
+    OPT_FUSED_LAYER,     // 0: a GINE application as aggregate + two GEMM launches
+    OPT_FUSED_BWD,       // 0 / 1: the GINE MLPs' backward as two GEMMs / one launch
+    OPT_FUSED_SCORER,    // 0: never one launch; 1: forward and backward always; 2: forward always
+    OPT_SPLIT_BF16,      // 0: fused kernels on the fp32 matrix instruction
+    OPT_SPLIT_ROWS,      // 32 / 64 nodes per workgroup of the cut-operand GINE kernels
+    OPT_SPLIT_GEMM,      // 0 / 1: 64-tile weight gradients on the fp32 / the cut-operand kernel
+    OPT_WIDE_GEMM,       // 0 / 1: 160-tile weight-gradient kernel never / wherever the shape allows
+    OPT_GRU_MULTI_CU,    // 0 / 1: single-CU / multi-CU recurrence
+    OPT_GRU_TILES,       // 1 / 2 / 4 sequence tiles per workgroup of the multi-CU recurrence
+    OPT_GRU_SPIN_TICKS,  // bound of a multi-CU recurrence wait in 10 ns ticks; 0: give up at once (tests the redo)
+    OPT_COUNT
+};
+int opt(int which);
+
 // ---------------------------------------------------------------- launch timer (profiler.hip)
 enum KernelClass {
     KC_GEMM_FWD = 0, KC_GEMM_DX, KC_GEMM_DW, KC_GEMM_REDUCE, KC_AGG_FWD, KC_AGG_BWD, KC_ETAB, KC_EMBED, KC_TABLE_GRAD,

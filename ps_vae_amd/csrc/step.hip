@@ -153,10 +153,7 @@ Stack dec_stack(const psvae_dims& d, const psvae_params& p, const psvae_params* 
 // Forward of 1 or 2 stacks with the same t: node_trans, then t x (aggregate, Linear+ReLU, Linear).
 // `packed` (or null): an event after which the stacks' packed weights are in place (written by the caller on
 // another stream); without it they are packed here.
-bool fused_layers_on() {
-    static const bool on = [] { const char* e = getenv("PSVAE_FUSED_LAYER"); return !(e && e[0] == '0'); }();
-    return on;
-}
+bool fused_layers_on() { return opt(OPT_FUSED_LAYER) != 0; }
 // The link scorer as one launch per direction (32 pairs per workgroup, one workgroup per CU) instead of the pair
 // gather, three GEMM launches and the head.  Forward alone: pays while all its workgroups fit the GPU in one round
 // (128 graphs: 135 workgroups, and the CUs it leaves free go to the recurrence beside it; +1.4 % on the fp32
@@ -165,11 +162,8 @@ bool fused_layers_on() {
 // at 1024; at 128 graphs the one-launch backward still loses 1.2 % (its one-per-CU workgroups keep the recurrence's
 // backward, which needs its workgroups resident together, waiting for CUs).  Default: forward fused up to 240
 // workgroups; both from 480 workgroups up when the cut-operand kernels are on.
-// PSVAE_FUSED_SCORER: 0 = never, 1 = forward and backward always, 2 = forward always.
-int fused_scorer_mode() {
-    static const int mode = [] { const char* e = getenv("PSVAE_FUSED_SCORER"); return e ? atoi(e) : -1; }();
-    return fused_layers_on() ? mode : 0;
-}
+// Option fused_scorer: 0 = never, 1 = forward and backward always, 2 = forward always.
+int fused_scorer_mode() { return fused_layers_on() ? opt(OPT_FUSED_SCORER) : 0; }
 bool fused_scorer_fwd_on(int S, int H) {
     const int m = fused_scorer_mode(), wgs = (S + 31) / 32;
     return m == 1 || m == 2 || (m < 0 && S > 0 && (wgs <= 240 || (gine_layer_split(H) && wgs >= 480)));
@@ -181,11 +175,11 @@ bool fused_scorer_bwd_on(int S, int H) {
 // The fused backward of the GINE MLPs.  On the fp32 matrix instruction it pays once a launch holds more row tiles
 // than the GPU has compute units (measured: -1.2 % at 128 graphs per step, +0.6 % at 256, +2.2 % at 512); on the
 // bf16 instruction over cut operands (gine_layer_split) its two products take half the time and it pays at every
-// size measured (+3 % at 128 graphs per step).  PSVAE_FUSED_BWD=0 / 1 forces it off / on.
+// size measured (+3 % at 128 graphs per step).  Option fused_bwd = 0 / 1 forces it off / on.
 bool fused_bwd_on(int n, int ng, int H) {
-    static const int forced = [] { const char* e = getenv("PSVAE_FUSED_BWD"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const int forced = opt(OPT_FUSED_BWD);
     if (!fused_layers_on()) return false;
-    if (forced >= 0) return forced == 1;
+    if (forced >= 0) return forced != 0;
     return gine_layer_split(H) || (long long)((n + 31) / 32) * ng >= 320;
 }
 int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int ng, bool save = true, hipEvent_t packed = nullptr) {
@@ -200,7 +194,7 @@ int stacks_forward(hipStream_t st, const Sz& s, const WS& w, const Stack* k, int
         d.scratch = w.scratch; d.scratch_floats = w.scratch_floats;
         PSVAE_TRY(gemm_f32(st, d));
     }
-    // one launch per GINE application where the fused kernel takes the size (PSVAE_FUSED_LAYER=0: three launches)
+    // one launch per GINE application where the fused kernel takes the size (option fused_layer = 0: three launches)
     const bool fused = fused_layers_on() && gine_layer_fused_supported(H, H, H);
     if (fused && packed) {
         if (hipStreamWaitEvent(st, packed, 0) != hipSuccess) return (int)hipGetLastError();
@@ -310,11 +304,11 @@ int stacks_edge_grads(hipStream_t st, const Sz& s, const WS& w, const Stack* k, 
 // piece/GRU branch and the property head run beside the link scorer, and weight-gradient
 // products run beside the input-gradient chain.  Fork and join are event waits on the
 // caller's stream, so from outside the call still behaves like work on that one stream.
-// Set PSVAE_STREAMS=0 to run everything on the caller's stream.
+// Option streams = 0 runs everything on the caller's stream.
 struct Lanes { hipStream_t s1, s2; hipEvent_t ev[17]; };
 std::mutex lanes_mu;
 Lanes* lanes_per_device[64] = {};
-int lanes_disabled = -1;
+bool lanes_unavailable = false;      // stream or event creation failed once: stay on the caller's stream
 
 bool create_lane(hipStream_t* s) {
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
@@ -344,8 +338,7 @@ bool lanes_overlap(hipStream_t a, hipStream_t b) {
 
 Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
     std::lock_guard<std::mutex> lock(lanes_mu);
-    if (lanes_disabled < 0) { const char* e = getenv("PSVAE_STREAMS"); lanes_disabled = (e && e[0] == '0') ? 1 : 0; }
-    if (lanes_disabled) return nullptr;
+    if (opt(OPT_STREAMS) == 0 || lanes_unavailable) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!lanes_per_device[dev]) {
@@ -361,9 +354,8 @@ Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
             break;
         }
         for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
-        if (probe && getenv("PSVAE_STREAMS_DEBUG")) fprintf(stderr, "psvae_streams_init: device %d, %d side stream(s) replaced\n", dev, nrej);
         for (int i = 0; ok && i < 17; ++i) ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { delete l; lanes_disabled = 1; return nullptr; }
+        if (!ok) { delete l; lanes_unavailable = true; return nullptr; }
         lanes_per_device[dev] = l;
     }
     return lanes_per_device[dev];
@@ -375,7 +367,7 @@ Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
 // (communicator, libraries) has created before.
 extern "C" int psvae_streams_init(void* stream) {
     Lanes* L = get_lanes(true, (hipStream_t)stream);
-    if (!L) return 0;       // lanes disabled (PSVAE_STREAMS=0) or unavailable: every call stays on the caller's stream
+    if (!L) return 0;       // lanes disabled (option streams = 0) or unavailable: every call stays on the caller's stream
     if (hipStreamSynchronize(L->s1) != hipSuccess || hipStreamSynchronize(L->s2) != hipSuccess)
         return (int)hipGetLastError();
     return 0;
@@ -634,9 +626,8 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     } else {
     // (With few pairs the three weight gradients are queued behind the whole input-gradient chain instead of each
     //  behind its own link: the chain, which the caller's stream waits for, then runs beside fewer competing
-    //  workgroups, and three hand-overs go - +0.5 % at 128 graphs, -0.7 % at 256.  PSVAE_SCORER_DW_LATE=0 / 1 forces.)
-    static const int late_forced = [] { const char* e = getenv("PSVAE_SCORER_DW_LATE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    const bool dw_late = late_forced >= 0 ? late_forced == 1 : s.S <= 6144;
+    //  workgroups, and three hand-overs go - +0.5 % at 128 graphs, -0.7 % at 256.)
+    const bool dw_late = s.S <= 6144;
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
     PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
     if (!fused_pair_head) PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
@@ -717,9 +708,8 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     //  batch is small: the caller's stream, which still has node_trans and the embedding tables to do, is then the
     //  last of the three to finish, +1.3 % at 128 graphs per step; at 1024 graphs the second of the two launches waits
     //  behind the long-running weight-gradient workgroups wherever it is queued, and in front of lane 2's products
-    //  it delays them: -0.6 %.  PSVAE_ETAB_LANE=0 / 1 forces the caller's stream / lane 2.)
-    static const int etab_forced = [] { const char* e = getenv("PSVAE_ETAB_LANE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    hipStream_t se = (etab_forced >= 0 ? etab_forced == 1 : s.n <= 12288) ? s2 : st;
+    //  it delays them: -0.6 %.)
+    hipStream_t se = s.n <= 12288 ? s2 : st;
     if (dec_only) {
         PSVAE_TRY(stacks_edge_grads(se, s, w, &k[1], 1, 1));
     } else if (s.te == s.td) {

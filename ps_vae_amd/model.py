@@ -216,6 +216,11 @@ class PSVAEModel(nn.Module):
             self._gflat.zero_()
             self._grads_fresh = True
 
+    @staticmethod
+    def trained_names():
+        """Names of the parameters the step trains, in the order of the flat buffers."""
+        return list(FLAT_ORDER)
+
     def flat_buffers(self):
         """(parameters, gradients) as flat fp32 tensors over the trained range."""
         self._sync_flat()
@@ -347,11 +352,10 @@ class PSVAEModel(nn.Module):
         return self._status
 
     def recurrence_gave_up(self, clear=False):
-        """True if, in any step since the model was built (or since the last call with `clear`), a workgroup of
-        the multi-CU GRU recurrence stopped waiting for its partners (its waits are bounded so that a GPU that
-        cannot keep the group resident cannot hang the process; that step's results are meaningless).  The
-        kernels set a status word that nothing clears in between, so one check covers every step so far.
-        Synchronises the device."""
+        """True if any step since the model was built (or since the last call with `clear`) left invalid results
+        behind (status word 0 of `psvae_batch.status`).  No kernel of the current library sets it: a multi-CU GRU
+        recurrence whose workgroups stop waiting for each other is redone on the single-CU kernels inside the same
+        step (`recurrence_redone`).  Synchronises the device."""
         if self._status is None:
             return False
         torch.cuda.synchronize(self._status.device)
@@ -359,6 +363,16 @@ class PSVAEModel(nn.Module):
         if clear:
             self._status.zero_()
         return gave_up
+
+    def recurrence_redone(self):
+        """Number of GRU recurrences (forward or backward) since the model was built that were redone on the single-CU
+        kernels because a workgroup of the multi-CU recurrence stopped waiting for its partners (bounded waits: a GPU
+        that cannot keep the group resident must not hang the process).  Results are valid either way; a non-zero
+        count means such steps took seconds.  Synchronises the device."""
+        if self._status is None:
+            return 0
+        torch.cuda.synchronize(self._status.device)
+        return int(self._status[1].item())
 
     def activation(self, name, rows, cols, ld=None):
         """View of a saved activation of the most recent forward (tests, debugging)."""

@@ -67,8 +67,51 @@ class FusedClipAdam:
         return a
 
     def state_dict(self):
-        return {'step': self.step_count, 'epoch': self.epoch, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+        """Step count, epoch and Adam's two moments PER PARAMETER NAME (views of the flat buffers): a checkpoint then
+        does not depend on the order in which this version lays the parameters out in its flat buffer."""
+        out = {'step': self.step_count, 'epoch': self.epoch, 'exp_avg': None, 'exp_avg_sq': None}
+        if self.exp_avg is not None:
+            model = self.model
+            model.flat_buffers()
+            named = dict(model.named_parameters())
+            for key, buf in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                out[key] = {k: buf[model._offsets[k]:model._offsets[k] + named[k].numel()].view(named[k].shape)
+                            for k in model.trained_names()}
+        return out
 
     def load_state_dict(self, sd):
-        self.step_count, self.epoch = sd['step'], sd['epoch']
-        self.exp_avg, self.exp_avg_sq = sd['exp_avg'], sd['exp_avg_sq']
+        """Accepts `state_dict()`'s per-name moments; a flat moment buffer (what versions before the per-name form
+        wrote) only together with `flat_order`, the list of parameter names in the order that buffer was laid out -
+        without it the buffer cannot be told apart from one in another order of the same length, and is refused."""
+        self.step_count, self.epoch = int(sd['step']), int(sd['epoch'])
+        if sd.get('exp_avg') is None:
+            self.exp_avg = self.exp_avg_sq = None
+            return
+        model = self.model
+        params, _ = model.flat_buffers()
+        named = dict(model.named_parameters())
+        new = {}
+        for key in ('exp_avg', 'exp_avg_sq'):
+            src = sd[key]
+            flat = torch.zeros_like(params)
+            if torch.is_tensor(src):
+                order = sd.get('flat_order')
+                if order is None:
+                    raise ValueError('optimizer state holds a flat moment buffer without its parameter order '
+                                     "('flat_order'): it cannot be mapped onto this version's layout")
+                if sorted(order) != sorted(model.trained_names()):
+                    raise ValueError("'flat_order' names other parameters than this model trains")
+                off, pieces = 0, {}
+                for k in order:
+                    pieces[k] = src[off:off + named[k].numel()]
+                    off += (named[k].numel() + 3) // 4 * 4
+                src = pieces
+            missing = [k for k in model.trained_names() if k not in src]
+            if missing:
+                raise ValueError(f'optimizer state lacks moments for {missing[:3]}...')
+            for k in model.trained_names():
+                o = model._offsets[k]
+                flat[o:o + named[k].numel()] = src[k].reshape(-1).to(params.device, torch.float32)
+            new[key] = flat
+        self.exp_avg, self.exp_avg_sq = new['exp_avg'], new['exp_avg_sq']
+        self.partials = None

@@ -57,10 +57,15 @@ def save_checkpoint(path, model, optimizer, epoch):
     ckpt = {
         'epoch': int(epoch), 'global_step': int(model.global_step),
         'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
+        # Adam's moments per parameter name (as torch's own optimisers key their state per parameter): the file does
+        # not depend on the order of this version's flat buffers
         'optimizer_states': [{'step': int(opt['step']), 'epoch': int(opt['epoch']),
-                              'exp_avg': None if opt['exp_avg'] is None else opt['exp_avg'].detach().cpu(),
-                              'exp_avg_sq': None if opt['exp_avg_sq'] is None else opt['exp_avg_sq'].detach().cpu()}],
+                              'exp_avg': None if opt['exp_avg'] is None else {k: v.detach().cpu().clone() for k, v in opt['exp_avg'].items()},
+                              'exp_avg_sq': None if opt['exp_avg_sq'] is None else {k: v.detach().cpu().clone() for k, v in opt['exp_avg_sq'].items()}}],
         'hyper_parameters': {'config': _plain(model.config)},
+        # where the counter-based epsilon draw of rsample stands: a resumed run goes on with fresh noise instead of
+        # replaying the first steps' draws
+        'eps_state': {'seed': int(model.eps_seed), 'draws': int(model.eps_draws)},
     }
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ckpt, path)
@@ -73,12 +78,10 @@ def load_checkpoint(path, model, optimizer=None):
     ckpt = torch.load(path, map_location='cpu', weights_only=True)
     model.load_state_dict(ckpt['state_dict'])
     model.global_step = int(ckpt.get('global_step', 0))
+    if 'eps_state' in ckpt:
+        model.eps_seed, model.eps_draws = int(ckpt['eps_state']['seed']), int(ckpt['eps_state']['draws'])
     if optimizer is not None and ckpt.get('optimizer_states'):
-        st = ckpt['optimizer_states'][0]
-        dev = model.flat_buffers()[0].device
-        optimizer.load_state_dict({'step': st['step'], 'epoch': st['epoch'],
-                                   'exp_avg': None if st['exp_avg'] is None else st['exp_avg'].to(dev),
-                                   'exp_avg_sq': None if st['exp_avg_sq'] is None else st['exp_avg_sq'].to(dev)})
+        optimizer.load_state_dict(ckpt['optimizer_states'][0])     # (refuses moments it cannot map by name)
     return int(ckpt.get('epoch', 0))
 
 
@@ -117,6 +120,8 @@ def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3
     dp = reducer is not None and reducer.active
     rank = torch.distributed.get_rank(reducer.group) if dp else 0
     writer = rank == 0
+    if dp:
+        model.shard_rank = rank      # batches without a recorded position (validation) draw epsilon rows of their own shard
     for epoch in range(max_epochs):
         opt.set_epoch(epoch)
         # a new order (and new negative pairs) every epoch, as DataLoader(shuffle=True) and the reference's
@@ -146,11 +151,15 @@ def fit(model, train_loader, valid_loader, max_epochs, save_dir=None, patience=3
                     reducer.reduce_grads(model.flat_buffers()[1])
                 opt.step()
             model.global_step += 1
-        # the multi-CU recurrence bounds its waits; a step in which a workgroup gave up holds garbage, and the
-        # parameters must not be validated or saved (checked here, where the host synchronises anyway)
+        # (checked here, where the host synchronises anyway; no kernel of the current library reports invalid results:
+        #  a multi-CU recurrence that times out is redone on the single-CU kernels inside the step)
         if model.recurrence_gave_up():
-            raise RuntimeError(f'epoch {epoch}: the multi-CU GRU recurrence timed out during a training step (GPU shared '
-                               'with another process?); parameters are invalid. Set PSVAE_GRU_MULTI_CU=0 on a shared GPU.')
+            raise RuntimeError(f'epoch {epoch}: a training step reported invalid results; parameters must not be kept')
+        redone = model.recurrence_redone()
+        if redone and log:
+            log({'epoch': epoch, 'gru_recurrences_redone_on_one_cu': redone,
+                 'hint': 'the GPU could not keep the multi-CU recurrence resident (shared with another process?); '
+                         "set option gru_multi_cu = 0 (PSVAE_GRU_MULTI_CU=0) to avoid the seconds-long waits"})
         rec = validate(model, valid_loader, device, reducer)
         rec.update(epoch=epoch, global_step=model.global_step)
         history.append(rec)

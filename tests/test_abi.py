@@ -62,6 +62,24 @@ def test_argument_errors_come_back_as_codes():
         _lib.check(-2, 'probe')
 
 
+def test_options_table():
+    """Kernel-selection options: every name the header documents exists, values can be set and read back inside one
+    process, -1 (and anything below) means "the library chooses", unknown names are an error code."""
+    L = _lib.lib()
+    names = _lib.option_names()
+    documented = re.findall(r'^ \*   ([a-z_0-9]+) +(?:-?\d|bound)', HEADER, flags=re.M)
+    assert sorted(names) == sorted(documented) and 'split_bf16' in names and 'gru_spin_ticks' in names
+    for n in names:
+        env = os.environ.get('PSVAE_' + n.upper())
+        old = _lib.set_option(n, 3)
+        assert old == (int(env) if env else -1)
+        assert _lib.set_option(n, -7) == 3
+        assert _lib.set_option(n, old) == -1
+    v = C.c_int(0)
+    assert L.psvae_option_set(b'no_such_option', 1) == -2 and L.psvae_option_get(b'no_such_option', C.byref(v)) == -2
+    assert L.psvae_option_get(b'streams', None) == -1
+
+
 def test_no_cpu_path():
     """Without a GPU the model raises: there is no CPU implementation behind the module surface."""
     from ps_vae_amd import PSVAEModel, Tokenizer, default_args, full_config

@@ -91,10 +91,11 @@ def test_stress_full_size_is_sum_of_its_parts():
     check_close(g_parts, g_whole, 'gradient of the whole batch vs sum over halves', rtol=1e-4, atol_scale=2e-5, bad_frac=1e-3)
 
 
-@pytest.mark.parametrize('B', [256, 512])
+@pytest.mark.parametrize('B', [256, 512, 1024])
 def test_vocab500_per_gpu_workloads_of_the_data_parallel_configuration(B):
-    """Vocabulary 500 with 256 and 512 graphs per GPU: what one GPU holds when the global batch of 1024 is split
-    over 4 and 2 of them.  A 48-graph slice of the batch is checked against the oracle (activations, losses,
+    """Vocabulary 500 with 256, 512 and 1024 graphs per GPU: what one GPU holds when the global batch of 1024 is split
+    over 4, 2 and 1 of them (at 1024 the single-CU recurrence, 64-node GINE workgroups, the one-launch scorer backward
+    and the 192-workgroup split of the 160-tile weight gradients are the defaults).  A 48-graph slice of the batch is checked against the oracle (activations, losses,
     all gradients); the whole batch through size-independent properties: its loss sums equal the sums over its
     four quarters, its gradient equals the quarters' gradients (each divided by the whole batch's counts, as the
     data-parallel step divides) added up, and two runs are bitwise identical."""

@@ -125,3 +125,48 @@ def test_sample_pieces_draws_from_the_softmax():
     first = np.array([s[0] for s in got])
     freq = np.bincount(first, minlength=V + 2)[:V] / len(first)
     assert np.abs(freq - p[:V]).max() < 4.0 * np.sqrt(p[:V].max() / len(first)) + 5e-3
+
+
+def _fixture_model(g):
+    """The model the generation fixtures were recorded with: seeded parameters plus the recorded bias shifts."""
+    d, V = g['dims'], g['vocab_size']
+    model, tok, sd = build(d, V, g['param_seed'])
+    with torch.no_grad():
+        model.decoder.to_vocab.bias[V + 1] += g.get('end_bias', 0.0)
+        model.decoder.edge_predictor[1].bias[0] += g.get('none_bias', 0.0)
+    return model, d
+
+
+def test_front_half_matches_the_reference_fixture():
+    """The batched GPU stages against what the reference's own `VAEPieceDecoder.inference` computed
+    (`tests/golden/inference.pt`, recorded by `tools/make_fixtures.py` from the reference's file): the pieces drawn
+    for every latent (same inversion rule at the recorded uniforms; cases whose draws fall near an interval boundary
+    are not in the file) and the link probabilities of the fragment sets."""
+    from tests.util import load_golden
+    from ps_vae_amd.inference import candidate_order, sample_pieces, score_links
+    g = load_golden('inference.pt')
+    model, d = _fixture_model(g)
+    cases = g['cases']
+    for c in cases:       # sampling: one call per (temperature, atom limit) setting
+        got = sample_pieces(model, c['z'].cuda().unsqueeze(0), c['max_atom_num'], c['temperature'],
+                            uniforms=c['uniforms'].cuda().unsqueeze(0), piece_atoms=g['piece_atoms'], check_every=0)
+        assert got[0] == c['drawn_ids'][:-1], (got[0], c['drawn_ids'])
+    with_pairs = [c for c in cases if c['pair_logits'] is not None]
+    frags = []
+    for c in with_pairs:
+        groups, start = [], 0
+        for pid in c['drawn_ids'][:-1]:
+            groups.append(list(range(start, start + g['piece_atoms'][pid])))
+            start += g['piece_atoms'][pid]
+        bonds = [e for e in c['edge_index'][::2]]          # each in-piece bond once (the loop appends both directions)
+        frags.append({'x': c['x'], 'x_pieces': c['x_pieces'], 'x_pos': c['x_pos'], 'bonds': bonds,
+                      'bond_types': c['edge_attr'][::2], 'groups': groups})
+    got = score_links(model, torch.stack([c['z'] for c in with_pairs]).cuda(), frags)
+    for c, r in zip(with_pairs, got):
+        want = torch.softmax(c['pair_logits'], dim=-1)
+        check_close(torch.from_numpy(r['probs']), want, 'link probabilities', rtol=2e-4, atol_scale=2e-5)
+        conf, typ = want.max(dim=-1)
+        top2 = want.topk(2, dim=-1).values
+        if bool(((top2[:, 0] - top2[:, 1]) > 1e-4).all()):       # no near-tie between two bond classes
+            order = candidate_order(r, c['add_edge_th'])
+            assert [int(r['bond_type'][j]) for j in order] == [t for t, _ in c['tried']]

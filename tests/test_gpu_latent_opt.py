@@ -28,3 +28,24 @@ def test_direct_optimize_rows_follow_the_reference_loop(target):
     with torch.no_grad():
         first = direct_optimize(model, z0.cuda(), target, lr=lr, max_iter=1, patience=patience)[1]
     assert float(best_loss.mean()) < float(first.mean())
+
+
+def test_direct_optimize_matches_the_reference_fixture():
+    """All nine recorded runs of the reference's own `generate.direct_optimize` (`tests/golden/latent_opt.pt`) as rows of
+    batched calls: step counts of the patience rule, best loss and the returned z."""
+    from tests.util import load_golden
+    from ps_vae_amd.latent_opt import direct_optimize
+    g = load_golden('latent_opt.pt')
+    model, tok, sd = build(g['dims'], g['vocab_size'], g['param_seed'])
+    cases = g['cases']
+    settings = sorted({(tuple(c['target']), c['lr'], c['max_iter'], c['patience']) for c in cases}, key=str)
+    assert len(settings) == 3
+    for target, lr, max_iter, patience in settings:
+        rows = [c for c in cases if (tuple(c['target']), c['lr'], c['max_iter'], c['patience']) == (target, lr, max_iter, patience)]
+        z0 = torch.stack([c['z0'] for c in rows]).cuda()
+        best_z, best_loss, steps = direct_optimize(model, z0, list(target), lr=lr, max_iter=max_iter, patience=patience)
+        for i, c in enumerate(rows):
+            assert int(steps[i]) == len(c['losses']), (i, int(steps[i]), len(c['losses']))
+            want = min(c['losses'])
+            assert abs(float(best_loss[i]) - want) <= 1e-4 * max(1e-3, abs(want)) + 1e-7
+            check_close(best_z[i], c['best_z'], f'best z of run {i}', rtol=1e-4, atol_scale=1e-4)

@@ -20,6 +20,19 @@ def _rand(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
+def check_fp32_accuracy(got, fp32_ref, exact, what):
+    """The kernels that run their products on the bf16 matrix instruction over operands cut into three bf16 pieces
+    claim fp32 accuracy.  Held to the float64 result `exact`, `got` must be as close as plain fp32 arithmetic
+    (`fp32_ref`: torch on the CPU, same operands) gets: largest error relative to the tensor's largest magnitude at
+    most 1.1 times that of the fp32 reference, plus 5e-8 (a tenth of one fp32 rounding)."""
+    exact = exact.double().cpu()
+    scale = max(float(exact.abs().max()), 1e-30)
+    err_gpu = float((got.detach().double().cpu().reshape(exact.shape) - exact).abs().max()) / scale
+    err_f32 = float((fp32_ref.detach().double().cpu().reshape(exact.shape) - exact).abs().max()) / scale
+    print(f'{what}: max error vs float64 / max magnitude: GPU {err_gpu:.2e}, fp32 torch {err_f32:.2e} ({err_gpu / max(err_f32, 1e-30):.2f}x)')
+    assert err_gpu <= 1.1 * err_f32 + 5e-8, (what, err_gpu, err_f32)
+
+
 @pytest.mark.parametrize('M,N,K,relu', [
     (2964, 300, 200, False), (2964, 300, 300, True), (128, 400, 1200, False), (128, 112, 400, False),
     (1, 5, 7, True), (67, 42, 16, False), (3000, 4, 656, False), (1408, 302, 200, False), (130, 66, 130, True),
@@ -300,7 +313,13 @@ def test_gine_layer_fused_forward(n, E, H, save):
                                       st) == -4      # scratch too small
 
 
-@pytest.mark.parametrize('S,n,B', [(3000, 2964, 128), (17, 40, 3), (1, 5, 1), (4113, 600, 33)])
+def _scorer_weights(P, P2):
+    return (_rand(P2, P, seed=3, scale=P ** -0.5), _rand(P2, seed=4, scale=0.1), _rand(P2, P2, seed=5, scale=P2 ** -0.5),
+            _rand(P2, seed=6, scale=0.1), _rand(P, P2, seed=7, scale=P2 ** -0.5), _rand(P, seed=8, scale=0.1),
+            _rand(4, P, seed=9, scale=P ** -0.5), _rand(4, seed=10, scale=0.1))
+
+
+@pytest.mark.parametrize('S,n,B', [(3000, 2964, 128), (17, 40, 3), (1, 5, 1), (4113, 600, 33), (16001, 11000, 480)])
 def test_scorer_fused_forward(S, n, B):
     """The link scorer's forward pass in one launch (gather, three Linear layers, Linear(P, 4), cross-entropy
     rows) against plain fp32 torch, including every activation it leaves behind for backward."""
@@ -313,10 +332,7 @@ def test_scorer_fused_forward(S, n, B):
     emb, z = _rand(n, H, seed=1), _rand(B, Z, seed=2)
     src, dst = torch.randint(0, n, (S,), generator=g), torch.randint(0, n, (S,), generator=g)
     gr, gold = torch.randint(0, B, (S,), generator=g), torch.randint(0, 4, (S,), generator=g)
-    w0, b0 = _rand(P2, P, seed=3, scale=P ** -0.5), _rand(P2, seed=4, scale=0.1)
-    w1, b1 = _rand(P2, P2, seed=5, scale=P2 ** -0.5), _rand(P2, seed=6, scale=0.1)
-    w2, b2 = _rand(P, P2, seed=7, scale=P2 ** -0.5), _rand(P, seed=8, scale=0.1)
-    w3, b3 = _rand(4, P, seed=9, scale=P ** -0.5), _rand(4, seed=10, scale=0.1)
+    w0, b0, w1, b1, w2, b2, w3, b3 = _scorer_weights(P, P2)
     pin_ref = torch.cat([emb[src], emb[dst], z[gr]], -1)
     h1_ref = torch.relu(F.linear(pin_ref, w0, b0))
     h2_ref = torch.relu(F.linear(h1_ref, w1, b1))
@@ -337,6 +353,90 @@ def test_scorer_fused_forward(S, n, B):
                                ('pair_in', 'h1', 'h2', 'h3', 'logits', 'row_loss', 'lse')):
         check_close(got, want, name, atol_scale=2e-5)
     assert torch.equal(out[0].cpu(), pin_ref)           # the gather copies bits
+    # fp32 accuracy of the three chained products on cut operands: h3 against its float64 value
+    h1_64 = torch.relu(F.linear(pin_ref.double(), w0.double(), b0.double()))
+    h2_64 = torch.relu(F.linear(h1_64, w1.double(), b1.double()))
+    h3_64 = F.linear(h2_64, w2.double(), b2.double())
+    check_fp32_accuracy(out[3], h3_ref, h3_64, f'scorer forward S={S}: h3')
+    check_fp32_accuracy(out[1], h1_ref, h1_64, f'scorer forward S={S}: h1')
+
+
+@pytest.mark.parametrize('S', [16001, 3000, 17, 1])
+def test_scorer_fused_backward(S):
+    """Backward of the link scorer's three Linear layers in ONE launch (`psvae_scorer_backward`) against plain fp32
+    torch autograd on the same inputs, and its fp32 accuracy against float64.  16 001 pairs = 501 workgroups: the size
+    from which the training step takes this kernel by itself."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    H, Z = 300, 56
+    P, P2 = 2 * H + Z, (2 * H + Z) // 2
+    w0, b0, w1, b1, w2, b2, _, _ = _scorer_weights(P, P2)
+    pin = _rand(S, P, seed=11)
+    dh3 = _rand(S, P, seed=12)
+
+    h1 = torch.relu(F.linear(pin, w0, b0))
+    h2 = torch.relu(F.linear(h1, w1, b1))
+    # what autograd derives for the pre-activations of the two hidden layers and for the input
+    x = pin.clone().requires_grad_()
+    a1 = F.linear(x, w0, b0)
+    a1.retain_grad()
+    a2 = F.linear(torch.relu(a1), w1, b1)
+    a2.retain_grad()
+    F.linear(torch.relu(a2), w2, b2).backward(dh3)
+    dh1_ref, dh2_ref, dpin_ref = a1.grad, a2.grad, x.grad
+    # the float64 yardstick takes the SAME gates (the saved fp32 activations decide them, as in the kernel)
+    dh2_64 = (dh3.double() @ w2.double()) * (h2 > 0)
+    dh1_64 = (dh2_64 @ w1.double()) * (h1 > 0)
+    dpin_64 = dh1_64 @ w0.double()
+    d = [t.to(dev()).contiguous() for t in (dh3, h2, h1, w0, w1, w2)]
+    out = [torch.full(shape, float('nan'), device=dev()) for shape in ((S, P2), (S, P2), (S, P))]
+    nbytes = L.psvae_scorer_scratch_bytes(H, Z)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    _lib.check(L.psvae_scorer_backward(*[t.data_ptr() for t in d], *[t.data_ptr() for t in out], S, H, Z,
+                                       scratch.data_ptr(), nbytes, st), 'psvae_scorer_backward')
+    for got, want, exact, name in zip(out, (dh2_ref, dh1_ref, dpin_ref), (dh2_64, dh1_64, dpin_64), ('d_h2', 'd_h1', 'd_pair_in')):
+        check_close(got, want, name, atol_scale=2e-5)
+        check_fp32_accuracy(got, want, exact, f'scorer backward S={S}: {name}')
+    assert L.psvae_scorer_backward(*[t.data_ptr() for t in d], *[t.data_ptr() for t in out], S, H, Z, scratch.data_ptr(),
+                                   nbytes - 16, st) == -4
+    assert L.psvae_scorer_backward(*[t.data_ptr() for t in d], *[t.data_ptr() for t in out], S, 512, Z, scratch.data_ptr(),
+                                   nbytes, st) == -2      # a size the one-launch kernels do not take
+
+
+@pytest.mark.parametrize('n,H,rows', [(2964, 300, -1), (24700, 300, -1), (5928, 300, 64), (700, 300, 32), (95, 300, -1),
+                                      (33, 64, -1), (1, 16, -1), (700, 512, -1), (5000, 328, -1), (40, 20, -1)])
+def test_gine_layer_fused_backward(n, H, rows):
+    """Backward of the two Linear layers of a GINE application in ONE launch (`psvae_gine_layer_backward`):
+    d_hid = (g w2) * [hid > 0], d_agg = d_hid w1, against fp32 torch and, for accuracy, float64; 32- and 64-node
+    workgroups as the library picks them by size and as option split_rows forces them."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g, hid = _rand(n, H, seed=1), _rand(n, H, seed=2)
+    w1, w2 = _rand(H, H, seed=5, scale=H ** -0.5), _rand(H, H, seed=7, scale=H ** -0.5)
+    dh_ref = (g @ w2) * (hid > 0)
+    da_ref = dh_ref @ w1
+    dh_64 = (g.double() @ w2.double()) * (hid > 0)
+    da_64 = dh_64 @ w1.double()
+    d = [t.to(dev()).contiguous() for t in (g, hid, w1, w2)]
+    dh = torch.full((n, H), float('nan'), device=dev())
+    da = torch.full((n, H), float('nan'), device=dev())
+    nbytes = L.psvae_gine_layer_scratch_bytes(H)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    old = _lib.set_option('split_rows', rows)
+    try:
+        _lib.check(L.psvae_gine_layer_backward(*[t.data_ptr() for t in d], dh.data_ptr(), da.data_ptr(), n, H,
+                                               scratch.data_ptr(), nbytes, st), 'psvae_gine_layer_backward')
+    finally:
+        _lib.set_option('split_rows', old)
+    check_close(dh, dh_ref, 'd_hid')
+    check_close(da, da_ref, 'd_agg')
+    check_fp32_accuracy(dh, dh_ref, dh_64, f'GINE backward n={n} H={H}: d_hid')
+    check_fp32_accuracy(da, da_ref, da_64, f'GINE backward n={n} H={H}: d_agg')
+    assert L.psvae_gine_layer_backward(*[t.data_ptr() for t in d], dh.data_ptr(), None, n, H, scratch.data_ptr(), nbytes, st) == -1
+    assert L.psvae_gine_layer_backward(*[t.data_ptr() for t in d], dh.data_ptr(), da.data_ptr(), n, H, scratch.data_ptr(),
+                                       nbytes - 16, st) == -4
 
 
 @pytest.mark.parametrize('nseg,M,N,K,bias', [(4, 5000, 300, 300, True), (1, 24000, 328, 656, True), (1, 17000, 656, 328, False),
@@ -362,10 +462,16 @@ def test_weight_gradient_over_long_reductions(nseg, M, N, K, bias):
     seg_dy, seg_x = (M * N, M * K) if nseg > 1 else (0, 0)
     _lib.check(L.psvae_linear_backward_weight(dy.data_ptr(), N, seg_dy, x.data_ptr(), K, seg_x, nseg, dw.data_ptr(),
                                               db.data_ptr() if bias else None, M, N, K, scratch.data_ptr(), nbytes, st))
-    want = torch.einsum('smn,smk->nk', dy.double(), x.double()).float()
+    exact = torch.einsum('smn,smk->nk', dy.double(), x.double())
+    want = exact.float()
     check_close(dw, want, 'dw', atol_scale=2e-5)
     if bias:
         check_close(db, dy.double().sum((0, 1)).float(), 'db', atol_scale=2e-5)
+    # fp32 accuracy of the cut-operand kernels (64-tile and 160-tile, with their split reductions): as close to the
+    # float64 product as torch's fp32 product of the same operands on the CPU
+    dy_c, x_c = dy.cpu(), x.cpu()
+    fp32 = sum(dy_c[i].t() @ x_c[i] for i in range(nseg))
+    check_fp32_accuracy(dw, fp32, exact, f'weight gradient {nseg}x{M}x{N}x{K}')
     # reproducible bit for bit, also with a scratch buffer that only holds a few slabs
     dw2 = torch.empty_like(dw)
     _lib.check(L.psvae_linear_backward_weight(dy.data_ptr(), N, seg_dy, x.data_ptr(), K, seg_x, nseg, dw2.data_ptr(),

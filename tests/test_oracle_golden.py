@@ -71,3 +71,72 @@ def test_model_oracle_matches_reference(case):
         for n, want in ref['params_after'].items():
             check_close(tr.p[n], want, f'step {s} param {n}', rtol=1e-5)
     assert list(O.accuracies(tr.p, d, batch, g['eps'][0])) == pytest.approx(g['accus_after'], abs=1e-6)
+
+
+def _generation_params(g):
+    sd = O.make_params(g['dims'], g['param_seed'])
+    V = g['vocab_size']
+    sd['decoder.to_vocab.bias'][V + 1] += g.get('end_bias', 0.0)
+    sd['decoder.edge_predictor.1.bias'][0] += g.get('none_bias', 0.0)
+    return sd
+
+
+def test_direct_optimize_oracle_matches_reference():
+    """`O.direct_optimize` against what the reference's `generate.direct_optimize` did (src/generate.py:67-89): the
+    loss of every step, the number of steps its patience rule allowed, and the z it returned."""
+    g = load_golden('latent_opt.pt')
+    sd, d = _generation_params(g), g['dims']
+    assert any(len(c['losses']) < c['max_iter'] for c in g['cases']), 'no case exercises the early stop'
+    assert any(None in c['target'] for c in g['cases'])
+    for i, c in enumerate(g['cases']):
+        losses = []
+        best_z, best_loss, steps = O.direct_optimize(sd, d, c['z0'], c['target'], c['lr'], c['max_iter'], c['patience'],
+                                                     tuple(g['selected_properties']), keep=losses)
+        assert steps == len(c['losses']), (i, steps, len(c['losses']))
+        for a, b in zip(losses, c['losses']):
+            assert abs(a - b) <= 1e-5 * max(abs(b), 1e-3) + 1e-8, (i, a, b)
+        assert abs(best_loss - min(c['losses'])) <= 1e-5 * max(min(c['losses']), 1e-3) + 1e-8
+        check_close(best_z, c['best_z'], f'case {i}: returned z', rtol=1e-5)
+
+
+def test_generation_front_half_oracle_matches_reference():
+    """`O.sample_pieces` and `O.score_links` against the reference's `VAEPieceDecoder.inference`
+    (src/modules/vae_piece_decoder.py:128-263) run from the reference's own file: the probability vector handed to the
+    sampler at every step, the pieces drawn, the candidate pairs and their softmax, and - through
+    `ps_vae_amd.inference.candidate_order` - the order in which the reference tried to add bonds."""
+    import numpy as np
+    from ps_vae_amd.inference import candidate_order, candidate_pairs, cnt_atom
+    g = load_golden('inference.pt')
+    sd, d = _generation_params(g), g['dims']
+    assert [cnt_atom(p) for p in g['pieces']] + [0, 0] == g['piece_atoms']
+    scored = tried = 0
+    for i, c in enumerate(g['cases']):
+        probs = []
+        kept = O.sample_pieces(sd, d, c['z'], g['piece_atoms'], c['max_atom_num'], c['temperature'], c['uniforms'], keep=probs)
+        assert kept == c['drawn_ids'][:-1], (i, kept, c['drawn_ids'])
+        check_close(torch.stack(probs), c['probs'], f'case {i}: sampling probabilities', rtol=1e-5, atol_scale=1e-6)
+        # the fragments the reference assembled from those pieces
+        assert c['x_pieces'] == [pid for pid in kept for _ in range(g['piece_atoms'][pid])]
+        groups, start = [], 0
+        for pid in kept:
+            groups.append(list(range(start, start + g['piece_atoms'][pid])))
+            start += g['piece_atoms'][pid]
+        assert c['x_pos'] == [k + 1 for k, grp in enumerate(groups) for _ in grp]
+        if c['pair_logits'] is None:
+            assert len(candidate_pairs(groups, len(c['x']))[0]) == 0
+            continue
+        idx, p_links = O.score_links(sd, d, c['z'], c['x'], c['x_pieces'], c['x_pos'], c['edge_index'], c['edge_attr'], groups)
+        want = torch.softmax(c['pair_logits'], dim=-1)
+        check_close(p_links, want, f'case {i}: link probabilities', rtol=1e-5, atol_scale=1e-6)
+        m, k = candidate_pairs(groups, len(c['x']))
+        assert np.array_equal(np.stack([m, k], 1), idx.numpy())
+        scored += len(m)
+        # the order the reference walked through the candidates: bond types of its valence checks, pairs it accepted
+        conf, typ = want.max(dim=-1)
+        links = {'confidence': conf.numpy(), 'bond_type': typ.numpy()}
+        order = candidate_order(links, c['add_edge_th'])
+        assert [int(typ[j]) for j in order] == [t for t, _ in c['tried']], i
+        accepted = [(int(m[j]), int(k[j])) for j, (_, ok) in zip(order, c['tried']) if ok]
+        assert accepted == [tuple(a) for a in c['accepted_pairs_in_order']], i
+        tried += len(order)
+    assert scored > 400 and tried > 300

@@ -52,16 +52,37 @@ def _total(sums, denoms, step):
     return O.weighted_loss(scaled, step), scaled
 
 
-def _setup(seed=91):
+def _setup(seed=91, n_mols=N_MOLS):
     d = O.default_dims(VOCAB, **DIMS)
     tok = Tokenizer.synthetic(VOCAB)
-    mols = synth.make_molecules(seed, 'qm9', VOCAB, N_MOLS)
+    mols = synth.make_molecules(seed, 'qm9', VOCAB, n_mols)
     p = {k: v.double() for k, v in O.make_params(d).items()}
     names = O.trainable_names(d)
     for n in names:
         p[n].requires_grad_(True)
-    eps = torch.randn(N_MOLS, d['latent'], generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    eps = torch.randn(n_mols, d['latent'], generator=torch.Generator().manual_seed(5), dtype=torch.float64)
     return d, tok, mols, p, names, eps
+
+
+def _model_layout(d, tok):
+    """The product's gradient message for a model of these sizes: parameter names in flat-buffer order, their
+    offsets (each tensor padded to a multiple of four floats), the four bucket bounds and the message length (four
+    spare floats behind the gradients carry the next batch's loss denominators)."""
+    from tests.util import config_from_dims
+    from ps_vae_amd import PSVAEModel
+    model = PSVAEModel(config_from_dims(d, tok), tok)
+    message, tail = model.grad_message()
+    return model.trained_names(), dict(model._offsets), list(model.bucket_bounds), message.numel()
+
+
+def _message_grads(p, layout):
+    names, offs, _, length = layout
+    out = torch.zeros(length, dtype=torch.float64)
+    for k in names:
+        g = p[k].grad
+        if g is not None:
+            out[offs[k]:offs[k] + g.numel()] = g.flatten()
+    return out
 
 
 def _flat_grads(p, names):
@@ -90,6 +111,59 @@ def _worker(rank, world, port, out_dir):
         torch.save({'flat': flat, 'denoms': denoms, 'total': float(share)}, os.path.join(out_dir, f'rank{rank}.pt'))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_message(rank, world, port, out_dir, n_mols):
+    """One rank of a step as `bench.py` / `trainer.fit` drive it: its shard of the global batch, loss sums over the
+    all-reduced denominators, the gradient message in the product's flat layout reduced in the three ranges
+    `OverlappedReducer` uses, the next batch's four local counts riding behind the gradients."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        d, tok, mols, p, names, eps = _setup(n_mols=n_mols)
+        layout = _model_layout(d, tok)
+        lo, hi = shard_range(n_mols, rank, world)
+        batch = _collate(mols[lo:hi], tok)
+        sums, counts = _loss_sums(p, d, batch, eps[lo:hi])
+        b = layout[2]
+        reducer = GradReducer([b[0], b[1], b[3], b[4] + 4])
+        denoms = reducer.reduce_denoms(counts)
+        total, _ = _total(sums, denoms, step=1500)
+        total.backward()
+        message = _message_grads(p, layout)
+        message[b[4]:] = counts            # (stands for the NEXT batch's counts)
+        reducer.reduce_grads(message)
+        torch.save({'message': message, 'denoms': denoms, 'shard': (lo, hi)}, os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_uneven_global_batch(tmp_path):
+    """World size 8 (the node's GPU count) over a global batch of 1001 graphs: shards of 126 and 125 graphs, the four
+    denominators, and the gradient message in the product's flat layout reduced in its three ranges with the
+    denominators of the next batch riding in the last one.  Every rank must end with the undivided batch's gradient."""
+    world, n_mols = 8, 1001
+    mp.spawn(_worker_message, args=(world, _free_port(), str(tmp_path), n_mols), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f'rank{r}.pt') for r in range(world)]
+    assert [g['shard'][1] - g['shard'][0] for g in got] == [126] + [125] * 7
+    d, tok, mols, p, names, eps = _setup(n_mols=n_mols)
+    layout = _model_layout(d, tok)
+    batch = _collate(mols, tok)
+    sums, counts = _loss_sums(p, d, batch, eps)
+    total, _ = _total(sums, counts, step=1500)
+    total.backward()
+    want = _message_grads(p, layout)
+    b = layout[2]
+    assert b[0] == 0 and b[0] < b[1] < b[2] < b[3] < b[4] and b[4] + 4 == layout[3]
+    scale = want.abs().max().item()
+    for r in range(world):
+        assert torch.equal(got[r]['denoms'], counts), 'all-reduced denominators differ from the global counts'
+        assert torch.equal(got[r]['message'][b[4]:], counts), 'the counts riding behind the gradients'
+        err = (got[r]['message'][:b[4]] - want[:b[4]]).abs().max().item()
+        assert err <= 1e-10 * scale, f'rank {r}: gradient differs by {err}'
+        assert torch.equal(got[r]['message'], got[0]['message']), 'ranks disagree after the all-reduce'
 
 
 def test_shard_range_covers_everything():

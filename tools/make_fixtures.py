@@ -278,8 +278,227 @@ def edge_case_mols(vocab_size):
     return [one, two, chain]
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Generation-side fixtures: the reference's own `direct_optimize` (src/generate.py:67-89) and the GPU-shaped stages of
+# `VAEPieceDecoder.inference` (src/modules/vae_piece_decoder.py:128-274), executed from the reference's files.
+#
+# `inference` builds an RDKit molecule while it runs.  RDKit is not installed, so the molecule bookkeeping it calls is
+# replaced by recording stand-ins (listed in `run_inference_case`); everything numerical - the GRU sampling loop, the
+# embeddings, the decoder-side GINE stack, the all-pairs selection mask, the link scorer, softmax, confidence order,
+# `valence_check` and the connected-block bookkeeping - is the reference's code.  `torch.multinomial`, whose random
+# stream cannot be reproduced outside torch, is replaced by inversion of the cumulative distribution at recorded
+# uniforms (the rule the library's sampler documents); the probabilities it was handed are recorded.
+
+PIECE_ATOMS = 'CNOSFP'
+
+
+def piece_table(vocab_size, seed=17):
+    """One chain-shaped fragment per piece id, written like a SMILES string of one-letter atoms ('C=CN', 'O', ...):
+    what `idx_to_piece` returns.  `cnt_atom` (src/utils/chem_utils.py:158-163) counts its letters."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(vocab_size):
+        n = rng.choice([1, 1, 2, 2, 3, 4])
+        sm = rng.choice(PIECE_ATOMS)
+        for _ in range(n - 1):
+            sm += rng.choice(['', '', '', '=']) + rng.choice(PIECE_ATOMS)
+        out.append(sm)
+    return out
+
+
+class _FakeAtom:
+    def __init__(self, sym): self.sym = sym
+    def GetSymbol(self): return self.sym
+
+
+class _FakeBond:
+    def __init__(self, a, b, t): self.a, self.b, self.t = a, b, t
+    def GetBeginAtomIdx(self): return self.a
+    def GetEndAtomIdx(self): return self.b
+    def GetBondType(self): return self.t
+
+
+class _FakeMol:
+    """What `smiles2molecule` hands to `inference`: atoms in string order, bonds along the chain."""
+
+    def __init__(self, smi):
+        from rdkit.Chem.rdchem import BondType
+        self.atoms, self.bonds, order = [], [], BondType.SINGLE
+        for c in smi:
+            if c == '=':
+                order = BondType.DOUBLE
+            elif c == '#':
+                order = BondType.TRIPLE
+            else:
+                if self.atoms:
+                    self.bonds.append(_FakeBond(len(self.atoms) - 1, len(self.atoms), order))
+                self.atoms.append(_FakeAtom(c))
+                order = BondType.SINGLE
+
+    def GetNumAtoms(self): return len(self.atoms)
+    def GetAtomWithIdx(self, i): return self.atoms[i]
+    def GetBonds(self): return self.bonds
+
+
+class _FakeRWMol:
+    """Stands for the molecule under construction: records what is added, answers nothing."""
+
+    def __init__(self): self.log = []
+    def AddAtom(self, a): self.log.append(('atom', a)); return len(self.log)
+    def AddBond(self, a, b, t): self.log.append(('bond', a, b, t))
+    def RemoveAtom(self, a): self.log.append(('remove', a))
+    def GetMol(self): return self
+
+
+class GenTokenizer(TokenizerStandIn):
+    def __init__(self, vocab_size):
+        super().__init__(vocab_size)
+        self.pieces = piece_table(vocab_size)
+
+    def idx_to_piece(self, idx):
+        return self.pieces[idx] if idx < self.V else ('<pad>' if idx == self.V else '<s>')
+
+
+def _generation_model(d, vocab_size, end_bias, none_bias=0.0):
+    tok = GenTokenizer(vocab_size)
+    model = PSVAEModel(reference_config(d, tok), tok)
+    sd = O.make_params(d, seed=2021)
+    model.load_state_dict(sd, strict=True)
+    with torch.no_grad():        # makes sequences end by themselves now and then, and "no bond" less than certain
+        model.decoder.to_vocab.bias[vocab_size + 1] += end_bias
+        model.decoder.edge_predictor[1].bias[0] += none_bias
+    model.eval()
+    return model, tok
+
+
+def run_latent_opt_case():
+    import generate                                    # the reference's src/generate.py
+    V = 60
+    d = O.default_dims(V)
+    model, tok = _generation_model(d, V, 0.0)
+    g = torch.Generator().manual_seed(4)
+    cases = []
+    for target, lr, max_iter, patience in [([0.9, None, 0.3], 0.1, 40, 3), ([None, None, 0.5], 0.1, 40, 3),
+                                           ([0.2, None, None], 0.05, 25, 1)]:
+        for _ in range(3):
+            z0 = torch.randn(d['latent'], generator=g)
+            losses = []
+            real_log = generate.print_log
+            generate.print_log = lambda msg, level='INFO', _l=losses: _l.append(float(msg.split('loss: ')[1].split(',')[0]))
+            try:
+                best_z = generate.direct_optimize(model, z0, target, lr, max_iter, patience, 0, 0.0, 1.0)
+            finally:
+                generate.print_log = real_log
+            with torch.no_grad():
+                props0 = model.predict_props(z0)
+                loss0 = float(generate.get_loss(model, props0, target))
+            assert abs(loss0 - losses[0]) <= 1e-6 * max(1.0, abs(loss0))
+            cases.append({'z0': z0, 'target': target, 'lr': lr, 'max_iter': max_iter, 'patience': patience,
+                          'best_z': best_z.detach().clone(), 'losses': losses, 'props0': props0.detach().clone()})
+    out = {'dims': d, 'vocab_size': V, 'param_seed': 2021, 'selected_properties': [0, 2], 'cases': cases}
+    path = os.path.join(ROOT, 'tests', 'golden', 'latent_opt.pt')
+    torch.save(out, path)
+    print('latent_opt', [(len(c['losses']), round(min(c['losses']), 5)) for c in cases], 'size', os.path.getsize(path))
+
+
+def run_inference_case():
+    import modules.vae_piece_decoder as ref_dec       # the reference's module, whose globals get the stand-ins
+    V, end_bias, none_bias = 60, 2.0, -0.15
+    d = O.default_dims(V)
+    model, tok = _generation_model(d, V, end_bias, none_bias)
+    dec = model.decoder
+    rec = {}
+
+    class _Chem:
+        RWMol = _FakeRWMol
+        Atom = staticmethod(lambda sym: sym)
+        SanitizeMol = staticmethod(lambda m: None)
+        Kekulize = staticmethod(lambda m: None)
+
+    def fake_multinomial(probs, num_samples=1):
+        step = len(rec['probs'])
+        rec['probs'].append(probs.detach().clone())
+        rec['_pick'] = True
+        cdf = torch.cumsum(probs.double(), dim=0)
+        target = float(rec['uniforms'][step]) * float(cdf[-1])
+        idx = min(int(torch.searchsorted(cdf, torch.tensor(target, dtype=torch.double), right=True)), probs.numel() - 1)
+        gap = float((cdf - target).abs().min())
+        rec['margin'] = min(rec['margin'], gap)
+        rec['ids'].append(idx)
+        return torch.tensor([idx], dtype=torch.long)
+
+    def fake_cycle_check(i, j, mol):
+        rec['accepted'].append((int(i), int(j)))
+        return True
+
+    saved = {k: getattr(ref_dec, k) for k in ('Chem', 'smiles2molecule', 'cycle_check')}
+    real_multinomial, real_valence = torch.multinomial, ref_dec.valence_check
+
+    def spy_valence(a1, a2, e1, e2, new_edge, vocab, c1=0, c2=0):
+        ok = real_valence(a1, a2, e1, e2, new_edge, vocab, c1, c2)
+        rec['tried'].append((int(new_edge), bool(ok)))
+        return ok
+    hooks = [dec.edge_predictor.register_forward_pre_hook(lambda m, i: rec.__setitem__('pair_in', i[0].detach().clone())),
+             dec.edge_predictor.register_forward_hook(lambda m, i, o: rec.__setitem__('pair_logits', o.detach().clone()))]
+    ref_dec.Chem, ref_dec.smiles2molecule, ref_dec.cycle_check = _Chem, (lambda smi, kekulize=True: _FakeMol(smi)), fake_cycle_check
+    ref_dec.valence_check = spy_valence
+    torch.multinomial = fake_multinomial
+    real_embed_atom, real_embed_node = dec.embed_atom, dec.graph_embedding.embed_node
+
+    def spy_embed_atom(a, p_, q):
+        rec.update(x=a.tolist(), x_pieces=p_.tolist(), x_pos=q.tolist())
+        return real_embed_atom(a, p_, q)
+
+    def spy_embed_node(x, edge_index, edge_attr):
+        rec.update(edge_index=edge_index.t().tolist(), edge_attr=edge_attr.argmax(-1).tolist() if edge_attr.numel() else [])
+        return real_embed_node(x, edge_index, edge_attr)
+    dec.embed_atom, dec.graph_embedding.embed_node = spy_embed_atom, spy_embed_node
+    g = torch.Generator().manual_seed(31)
+    cases = []
+    try:
+        for temperature, max_atoms, th in [(1.0, 25, 0.3), (0.7, 1000, 0.0), (1.5, 6, 0.5), (1.0, 12, 0.0), (1.0, 40, 0.1), (0.9, 18, 0.26)]:
+            for _ in range(2):
+                z = torch.randn(d['latent'], generator=g)
+                u = torch.rand(d['max_pos'], generator=g)
+                rec.clear()
+                rec.update(probs=[], ids=[], uniforms=u, margin=1.0, accepted=[], tried=[])
+                with torch.no_grad():
+                    mol = dec.inference(z, max_atoms, th, temperature)
+                if rec['margin'] < 1e-4:
+                    continue        # a draw within rounding distance of an interval boundary: no vector for a borderline pick
+                atoms = [a for kind, *a in mol.log if kind == 'atom']
+                in_piece = [(a, b, t) for kind, a, b, t in [e for e in mol.log if e[0] == 'bond'][:]]
+                cases.append({'z': z, 'uniforms': u, 'temperature': temperature, 'max_atom_num': max_atoms, 'add_edge_th': th,
+                              'probs': torch.stack(rec['probs']), 'drawn_ids': list(rec['ids']), 'n_atoms_added': len(atoms),
+                              'x': rec['x'], 'x_pieces': rec['x_pieces'], 'x_pos': rec['x_pos'],
+                              'edge_index': rec['edge_index'], 'edge_attr': rec['edge_attr'],
+                              'pair_logits': rec.get('pair_logits'),
+                              'pair_in_l2': None if rec.get('pair_in') is None else float(rec['pair_in'].double().norm()),
+                              'bonds_added_in_order': [(a, b, tok.chem_vocab.bond_to_idx(t)) for a, b, t in in_piece],
+                              'accepted_pairs_in_order': list(rec['accepted']), 'tried': list(rec['tried']),
+                              'removed': [a for kind, *a in mol.log if kind == 'remove']})
+    finally:
+        torch.multinomial = real_multinomial
+        ref_dec.valence_check = real_valence
+        del dec.embed_atom, dec.graph_embedding.embed_node
+        for k, v in saved.items():
+            setattr(ref_dec, k, v)
+        for h in hooks:
+            h.remove()
+    out = {'dims': d, 'vocab_size': V, 'param_seed': 2021, 'end_bias': end_bias, 'none_bias': none_bias, 'pieces': tok.pieces,
+           'piece_atoms': [ref_dec.cnt_atom(p) for p in tok.pieces] + [0, 0], 'cases': cases}
+    path = os.path.join(ROOT, 'tests', 'golden', 'inference.pt')
+    torch.save(out, path)
+    print('inference', [(c['probs'].shape[0], c['n_atoms_added'], None if c['pair_logits'] is None else c['pair_logits'].shape[0],
+                         len(c['tried']), len(c['accepted_pairs_in_order'])) for c in cases], 'size', os.path.getsize(path))
+
+
 def main():
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'generation':      # only the two generation-side files
+        run_latent_opt_case()
+        run_inference_case()
+        return
     # --- collate fixtures (bit-exact integer work)
     run_collate_case('qm9_b8', synth.make_molecules(11, 'qm9', 300, 8), 300, 2021)
     run_collate_case('zinc_b6', synth.make_molecules(12, 'zinc', 300, 6), 300, 7)
@@ -291,6 +510,8 @@ def main():
     run_model_case('small_t3', dict(small, t_enc=3, t_dec=2), synth.make_molecules(22, 'qm9', 40, 5), 40)
     run_model_case('zinc_v300', O.default_dims(300), synth.make_molecules(23, 'zinc', 300, 4), 300)
     run_model_case('qm9_v500', O.default_dims(500), synth.make_molecules(24, 'qm9', 500, 6), 500)
+    run_latent_opt_case()
+    run_inference_case()
 
 
 if __name__ == '__main__':
