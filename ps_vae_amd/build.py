@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpsvae_hip.so')
 SOURCES = ['gemm.hip', 'fused_layer.hip', 'graph_kernels.hip', 'head_kernels.hip', 'gru.hip', 'step.hip', 'inference.hip', 'collate_device.hip', 'capi.hip', 'profiler.hip', 'rng.hip', 'collate.cpp']
-HEADERS = ['psvae_internal.h', os.path.join('..', '..', 'include', 'psvae.h')]
+HEADERS = ['psvae_internal.h', 'fused_device.h', os.path.join('..', '..', 'include', 'psvae.h')]
 
 
 def _stale():

@@ -20,15 +20,12 @@
 // the weights prefetched two blocks ahead.  Image pitch = 8 mod 64 floats: conflict-free ds_read_b128 for this
 // lane map (rows two apart land on disjoint 16-byte bank slots inside every 16-lane service group).
 #include "psvae_internal.h"
+#include "fused_device.h"
 #include <algorithm>
 
 namespace {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-constexpr int FL_ROWS = 32, FL_RT = 2, FL_NB = 8, FL_THREADS = 256;
-
-__device__ __forceinline__ float4 fl_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+constexpr int FL_ROWS = 32, FL_RT = 2;
 
 // Packed weights: [KB][4][Npad][4] floats, KB = ceil(K / 16) blocks, Npad = 64 CT columns (CT 16-column tiles for
 // each of the four waves).  `transposed`: the source holds W^T ([K][N] row-major, i.e. the product is x W instead
@@ -144,14 +141,6 @@ __device__ __forceinline__ void fl_product(const float* img, int P, const float*
     fl_product<CT, RT, false>(img, P, Wp, KB, wave, lane, acc, b0, b1);
 }
 
-template <int CT, int RT>
-__device__ __forceinline__ void fl_zero(floatx4 (&acc)[RT][CT]) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
-}
-
 // What a product leaves in the accumulators, plus bias (and ReLU), written to columns col0 + c of an LDS image
 // and/or of global rows row0 + r (< nrows).  An accumulator holds rows 4 (l >> 4) + i, column l & 15 of its tile.
 // ZERO_PAD: image columns from N up to the wave tiles' end are written as zeros (they are the next product's
@@ -198,12 +187,6 @@ __device__ __forceinline__ void fl_store(const floatx4 (&acc)[RT][CT], const flo
             }
         }
     }
-}
-
-template <int CT>
-__device__ __forceinline__ void fl_bias(const float* __restrict__ b, int N, int wave, int lane, float (&out)[CT]) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) out[ct] = b[min((wave * CT + ct) * 16 + (lane & 15), N - 1)];
 }
 
 struct FLGroup {
@@ -655,35 +638,6 @@ __global__ __launch_bounds__(FL_THREADS) void scorer_bwd_kernel(const ScorerBwdA
 // 256 contiguous bytes); the activations are cut as they are written into the LDS image, which holds three planes
 // [piece][row][pitch] of bf16 with a row pitch of an odd number of 16-byte units (conflict-free ds_read_b128 of
 // the fragments: lane l reads 8 consecutive k of row l & 15 at k quarter l >> 4).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned bf_bits(float x) {              // round to nearest even (v_cvt_pk_bf16_f32)
-    const __bf16 b = (__bf16)x;
-    return (unsigned)__builtin_bit_cast(unsigned short, b);
-}
-__device__ __forceinline__ void bf_cut(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = bf_bits(x);
-    const float r1 = x - __uint_as_float(h << 16);                 // exact: at most 16 significand bits, |r1| <= 2^-9 |x|
-    m = bf_bits(r1);
-    const float r2 = r1 - __uint_as_float(m << 16);                // exact: at most 7 significand bits, |r2| <= 2^-18 |x|
-    l = bf_bits(r2);                                               // exact
-}
-// four consecutive k of one row into the three planes (8 bytes each)
-__device__ __forceinline__ void bf_put4(char* img, int plane, int off, float4 v) {
-    unsigned h[4], m[4], l[4];
-    bf_cut(v.x, h[0], m[0], l[0]); bf_cut(v.y, h[1], m[1], l[1]); bf_cut(v.z, h[2], m[2], l[2]); bf_cut(v.w, h[3], m[3], l[3]);
-    *reinterpret_cast<uint2*>(img + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    *reinterpret_cast<uint2*>(img + plane + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    *reinterpret_cast<uint2*>(img + 2 * plane + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-}
-__device__ __forceinline__ void bf_put1(char* img, int plane, int off, float v) {
-    unsigned h, m, l;
-    bf_cut(v, h, m, l);
-    *reinterpret_cast<unsigned short*>(img + off) = (unsigned short)h;
-    *reinterpret_cast<unsigned short*>(img + plane + off) = (unsigned short)m;
-    *reinterpret_cast<unsigned short*>(img + 2 * plane + off) = (unsigned short)l;
-}
-
 struct PackSplitOne { const float* src; char* dst; int N, K, ld, transposed, Npad, KB; };
 struct PackSplitArgs { PackSplitOne m[8]; int count; };
 
@@ -706,208 +660,6 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(const PackSplit
         *reinterpret_cast<uint4*>(out) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
         *reinterpret_cast<uint4*>(out + pstride) = make_uint4(mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16));
         *reinterpret_cast<uint4*>(out + 2 * pstride) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-    }
-}
-
-__device__ __forceinline__ float4 fl_ld16(const char* p) { return *reinterpret_cast<const float4*>(p); }
-
-// blocks 0 and 1 of a product's weights, requested ahead of the phase in front of the product
-template <int CT>
-__device__ __forceinline__ void flb_prefetch(const char* __restrict__ Wp, int KB, int wave, int lane, float4 (&h0)[3][CT], float4 (&h1)[3][CT]) {
-    constexpr int Npad = 64 * CT;
-    const char* wlane = Wp + ((size_t)(lane >> 4) * Npad + wave * CT * 16 + (lane & 15)) * 16;
-    const char* p1 = wlane + (size_t)min(1, KB - 1) * (3 * 4 * Npad * 16);
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) h0[p][ct] = fl_ld16(wlane + ((size_t)p * 4 * Npad + ct * 16) * 16);
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) h1[p][ct] = fl_ld16(p1 + ((size_t)p * 4 * Npad + ct * 16) * 16);
-}
-
-// acc[rt][ct] += image rows of tile rt . W columns of tile ct over KB blocks of 32 reduction indices.  On entry
-// b0 / b1 hold (or have requested) the weights of blocks 0 / 1.  Every block's weights are requested a block and a
-// half ahead, its image rows half a block ahead.
-template <int CT, int RT>
-__device__ __forceinline__ void flb_product(const char* img, int PB, int plane, const char* __restrict__ Wp, int KB, int wave, int lane,
-                                            floatx4 (&acc)[RT][CT], float4 (&b0)[3][CT], float4 (&b1)[3][CT]) {
-    const int nl = lane & 15, kq = lane >> 4;
-    constexpr int Npad = 64 * CT;
-    const char* wlane = Wp + ((size_t)kq * Npad + wave * CT * 16 + nl) * 16;
-    const char* arow = img + nl * PB + kq * 16;
-    float4 a0[3][RT], a1[3][RT];
-#define FLB_LOADB(B_, KB_)                                                                                  \
-    {                                                                                                       \
-        const char* p_ = wlane + (size_t)min((KB_), KB - 1) * (3 * 4 * Npad * 16);                          \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                       \
-            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                               \
-                B_[p][ct] = fl_ld16(p_ + ((size_t)p * 4 * Npad + ct * 16) * 16);                            \
-    }
-#define FLB_READA(A_, KB_)                                                                                  \
-    {                                                                                                       \
-        const int o_ = min((KB_), KB - 1) * 64;                                                             \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                       \
-            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                               \
-                A_[p][rt] = *reinterpret_cast<const float4*>(arow + p * plane + rt * 16 * PB + o_);         \
-    }
-#define FLB_TERM(ACC_, A_, PA_, B_, PB_)                                                                    \
-    _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                       \
-        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                   \
-            ACC_[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_[PA_][rt]), \
-                                                                   __builtin_bit_cast(bf16x8, B_[PB_][ct]), ACC_[rt][ct], 0, 0, 0);
-    // The instruction rounds its accumulator as it adds, at the accumulator's magnitude whatever the size of the
-    // terms: the five small products therefore go to an accumulator of their own (2^-9 of the main one, and so are
-    // its roundings) that joins the main one once, at the end - the main accumulator is rounded as often as a chain
-    // of fp32 multiply-adds rounds, not six times as often.
-    floatx4 lo[RT][CT];
-    fl_zero<CT, RT>(lo);
-    // One block's matrix instructions with the loads of the block two ahead dealt in between them: a wave issues in
-    // order, and the packed weights arrive through the CU's vector-memory path at about the rate the matrix pipe
-    // consumes them (a 1-KiB wave load per four to six matrix instructions), so requests queued behind a block's
-    // instructions leave the pipe idle while they are issued.  The piece products are ordered so that a plane of the
-    // weights is free as early as possible: l first (one product), then m (two), then h (three); each plane's
-    // registers are reloaded right behind its last product.
-#define FLB_LOADP(B_, KB_, P_)                                                                              \
-    {                                                                                                       \
-        const char* p_ = wlane + (size_t)min((KB_), KB - 1) * (3 * 4 * Npad * 16);                          \
-        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                   \
-            B_[P_][ct] = fl_ld16(p_ + ((size_t)(P_) * 4 * Npad + ct * 16) * 16);                            \
-    }
-#define FLB_MFMA(A_, B_, KBN_)                                                                              \
-    {                                                                                                       \
-        FLB_TERM(lo, A_, 0, B_, 2) FLB_LOADP(B_, KBN_, 2)                                                   \
-        FLB_TERM(lo, A_, 1, B_, 1) FLB_TERM(lo, A_, 0, B_, 1) FLB_LOADP(B_, KBN_, 1)                        \
-        FLB_TERM(lo, A_, 2, B_, 0) FLB_TERM(lo, A_, 1, B_, 0) FLB_TERM(acc, A_, 0, B_, 0) FLB_LOADP(B_, KBN_, 0) \
-        __builtin_amdgcn_sched_group_barrier(0x008, RT * CT, 0);                                            \
-        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT, 0);                                         \
-        }                                                                                                   \
-        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * RT, 0);                                         \
-        }                                                                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);                                                 \
-    }
-    // Everything requested so far - the two prefetched blocks and whatever the phase in front of the product left in
-    // flight - is waited for HERE, once: a wait in the loop is one instruction for the first and for every later
-    // iteration, and with older requests pending on entry the compiler sizes it for those (all but one load complete),
-    // which in every later iteration exposes the latency of the block requested half an iteration earlier.
-    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
-    FLB_READA(a0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int kb = 0; kb < KB; kb += 2) {        // (the guards are uniform and hold no loads the next block needs)
-        FLB_READA(a1, kb + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        FLB_MFMA(a0, b0, kb + 2)
-        __builtin_amdgcn_sched_barrier(0);
-        FLB_READA(a0, kb + 2)
-        __builtin_amdgcn_sched_barrier(0);
-        if (kb + 1 < KB) FLB_MFMA(a1, b1, kb + 3)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += lo[rt][ct];
-#undef FLB_MFMA
-#undef FLB_LOADP
-#undef FLB_TERM
-#undef FLB_READA
-#undef FLB_LOADB
-}
-
-// fl_store for a split image: the same values, cut into the three planes (2-byte stores)
-template <int CT, int RT, bool RELU, bool ZERO_PAD>
-__device__ __forceinline__ void flb_store(const floatx4 (&acc)[RT][CT], const float (&bias)[CT], int N, char* img, int PB, int plane,
-                                          int kpad, float* gout, size_t ldg, int row0, int nrows, int wave, int lane) {
-    const int nl = lane & 15, kq = lane >> 4;
-    const bool full = row0 + 16 * RT <= nrows;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int c = (wave * CT + ct) * 16 + nl;
-        const bool cok = c < N;
-        float v[RT][4];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = acc[rt][ct][i] + bias[ct];
-                if (RELU) x = fmaxf(x, 0.f);
-                v[rt][i] = cok ? x : 0.f;
-            }
-        if (img && (cok || (ZERO_PAD && c < kpad))) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bf_put1(img, plane, (rt * 16 + 4 * kq + i) * PB + 2 * c, v[rt][i]);
-        }
-        if (gout && cok) {
-            float* q = gout + (size_t)(row0 + 4 * kq) * ldg + c;
-            if (full) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
-            } else {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (row0 + rt * 16 + 4 * kq + i < nrows) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
-            }
-        }
-    }
-}
-
-template <int CT, int RT, bool SYNC>
-__device__ __forceinline__ void flb_store_gated(const floatx4 (&acc)[RT][CT], const float* __restrict__ act, size_t ldact, int N,
-                                                char* img, int PB, int plane, int kpad, float* gout, size_t ldg, int row0, int nrows,
-                                                int wave, int lane) {
-    const int nl = lane & 15, kq = lane >> 4;
-    float gate[RT][CT][4];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int c = min((wave * CT + ct) * 16 + nl, N - 1);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gate[rt][ct][i] = act[(size_t)min(row0 + rt * 16 + 4 * kq + i, nrows - 1) * ldact + c];
-    }
-    if (SYNC) __syncthreads();
-    const bool full = row0 + 16 * RT <= nrows;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int c = (wave * CT + ct) * 16 + nl;
-        const bool cok = c < N;
-        float v[RT][4];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[rt][i] = (cok && gate[rt][ct][i] > 0.f) ? acc[rt][ct][i] : 0.f;
-        if (c < kpad) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bf_put1(img, plane, (rt * 16 + 4 * kq + i) * PB + 2 * c, v[rt][i]);
-        }
-        if (cok) {
-            float* q = gout + (size_t)(row0 + 4 * kq) * ldg + c;
-            if (full) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
-            } else {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (row0 + rt * 16 + 4 * kq + i < nrows) q[(size_t)(rt * 16 + i) * ldg] = v[rt][i];
-            }
-        }
     }
 }
 
@@ -1087,7 +839,6 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_split_kernel(const 
     flb_store<CT, RT, false, false>(acc, nobias, H, nullptr, 0, 0, 0, g.da, H, row0, n, wave, lane);
 }
 
-int flb_pitch_bytes(int K) { return (K + 31) / 32 * 64 + 16; }     // an odd number of 16-byte units
 // The link scorer's two kernels on cut operands.  ScorerArgs / ScorerBwdArgs as above with PA, PB = the split
 // images' row pitches in BYTES for reductions over P and P/2 and P3 = the pitch in floats of the fp32 image of s3
 // (which only the head reads).  The LDS regions are reused as the data in them dies: the pair input's planes
