@@ -379,8 +379,11 @@ __device__ __forceinline__ void fl_store_gated(const floatx4 (&acc)[RT][CT], con
 // W2 and W1 arrive packed in their transposed role (reduction over the weight matrix's ROW index).  dHid (needed by
 // the weight gradients of the first Linear) and dAgg (input of the aggregation's backward) go to memory; dHid never
 // comes back from there.
-struct FLBGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; };
-struct FLBArgs { FLBGroup g[2]; int n, H, P; };
+// `dpool` (or null): the rows of G are not read from `g` but are the pooled-output gradient of each row's graph,
+// dpool[node_graph[row] * ldp + column] (the top of the encoder stack: what the graph sum's backward broadcasts), and
+// the kernel writes them to `g` on the way, where the weight gradients read them (cut-operand kernel only).
+struct FLBGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; const float* dpool; };
+struct FLBArgs { FLBGroup g[2]; int n, H, P; const int32_t* node_graph; int ldp; };
 
 template <int CT>
 __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_kernel(const FLBArgs a) {
@@ -807,15 +810,17 @@ __global__ __launch_bounds__(FL_THREADS) void gine_layer_bwd_split_kernel(const 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int t = min(it + u * FL_THREADS, items - 1);
-                const int r = t / H4, c = (t - r * H4) * 4;
-                v[u] = fl_ld4(g.g + (size_t)min(row0 + r, n - 1) * H + c);
+                const int r = t / H4, c = (t - r * H4) * 4, row = min(row0 + r, n - 1);
+                v[u] = g.dpool ? fl_ld4(g.dpool + (size_t)a.node_graph[row] * a.ldp + c) : fl_ld4(g.g + (size_t)row * H + c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int t = it + u * FL_THREADS;
                 if (t >= items) continue;
                 const int r = t / H4, c = (t - r * H4) * 4;
-                bf_put4(img, plane, r * PB + 2 * c, row0 + r < n ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+                const bool live = row0 + r < n;
+                bf_put4(img, plane, r * PB + 2 * c, live ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+                if (g.dpool && live) *reinterpret_cast<float4*>(const_cast<float*>(g.g) + (size_t)(row0 + r) * H + c) = v[u];
             }
         }
         const int padw = kpad - H;
@@ -1280,7 +1285,7 @@ int scorer_fwd_fused(hipStream_t s, const ScorerFwd& f) {
     return 0;
 }
 
-int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, int H) {
+int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, int H, const int32_t* node_graph, int ldp) {
     if (n <= 0) return 0;
     if (ng < 1 || ng > 2) return PSVAE_E_SHAPE;
     if (!gine_layer_fused_supported(H, H, H)) return PSVAE_E_SHAPE;
@@ -1288,9 +1293,11 @@ int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, 
     for (int q = 0; q < ng; ++q) {
         const FusedLayerBwdGroup& f = grp[q];
         if (!f.g || !f.hid || !f.w2tp || !f.w1tp || !f.dh || !f.da) return PSVAE_E_NULL;
-        if (!aligned16(f.g) || !aligned16(f.w2tp) || !aligned16(f.w1tp)) return PSVAE_E_ALIGN;
-        a.g[q] = FLBGroup{f.g, f.hid, f.w2tp, f.w1tp, f.dh, f.da};
+        if (!aligned16(f.g) || !aligned16(f.w2tp) || !aligned16(f.w1tp) || (f.dpool && !aligned16(f.dpool))) return PSVAE_E_ALIGN;
+        if (f.dpool && (!node_graph || ldp % 4 || !gine_layer_split(H))) return f.dpool && !node_graph ? PSVAE_E_NULL : PSVAE_E_SHAPE;
+        a.g[q] = FLBGroup{f.g, f.hid, f.w2tp, f.w1tp, f.dh, f.da, f.dpool};
     }
+    a.node_graph = node_graph; a.ldp = ldp;
     const bool split = gine_layer_split(H);
     a.n = n; a.H = H; a.P = split ? flb_pitch_bytes(H) : fl_pitch(H);
     const int rows = split ? split_rows(n, ng, H, 0) : FL_ROWS;

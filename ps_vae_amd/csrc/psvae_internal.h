@@ -35,6 +35,7 @@ enum Option {
     OPT_GRU_MULTI_CU,    // 0 / 1: single-CU / multi-CU recurrence
     OPT_GRU_TILES,       // 1 / 2 / 4 sequence tiles per workgroup of the multi-CU recurrence
     OPT_GRU_SPIN_TICKS,  // bound of a multi-CU recurrence wait in 10 ns ticks; 0: give up at once (tests the redo)
+    OPT_AGG_ITEMS,       // 1 / 2 items per pipeline stage of the aggregation kernels
     OPT_COUNT
 };
 int opt(int which);
@@ -127,8 +128,12 @@ struct FusedLayerGroup {
 bool gine_layer_fused_supported(int H, int ldx, int ldy);
 // Backward of the two Linear layers of a GINE application in one launch: dh = (g w2) * [hid > 0], da = dh w1, with
 // w2tp / w1tp packed by fused_pack with `transposed` set (all matrices [n, H] / [H, H]).
-struct FusedLayerBwdGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; };
-int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* g, int ngroups, int n, int H);
+// `dpool` (or null; cut-operand kernels only): the rows of g are not read but ARE the pooled-output gradient of the row's
+// graph, dpool[node_graph[row] * ldp + column] - the top of a stack whose output went through the graph sum - and the
+// kernel writes them to g on the way (the weight gradients read them there).
+struct FusedLayerBwdGroup { const float *g, *hid, *w2tp, *w1tp; float *dh, *da; const float* dpool = nullptr; };
+int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* g, int ngroups, int n, int H, const int32_t* node_graph = nullptr,
+                   int ldp = 0);
 // Weights as the fused kernels read them: a [N][K] matrix (row pitch ld; `transposed`: stored as [K][N]) re-laid as
 // [ceil(K/16)][4][Npad][4] so that a wave's operand fragment is four 256-byte runs; fused_pack_floats = its size.
 // `split`: three bf16 planes per 32 reduction indices instead (the form the GINE kernels take when gine_layer_split(H) says so).

@@ -247,8 +247,10 @@ static float* etab_region(const Sz& s, const WS& w, int slot) {
 // Gr) holds dL/dx_t.  dpool[q] (or null) is the pooled-output gradient [B, t*H]
 // whose slice l-1 is broadcast into dL/dx_l.  Leaves dL/dx_0 of stack q in
 // w.G0[:, q*H:(q+1)*H] and writes the weight gradients of conv.nn and edge_trans.
+// `top_from_pool`: dL/dx_t of the stacks that have a dpool is not in Gr yet; the fused backward of the top layer takes it
+// from dpool's last slice itself (and writes it to Gr).
 int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch& b, const Stack* k, int ng,
-                    const float* const* dpool, int g0_slot0, int etab_slot0) {
+                    const float* const* dpool, int g0_slot0, int etab_slot0, bool top_from_pool = false) {
     const int n = s.n, H = s.H, t = k[0].t;
     const size_t nH = (size_t)n * H, nblk = (size_t)gine_agg_bwd_blocks(n, H);
     const int64_t dG = ng == 2 ? k[1].Gr - k[0].Gr : 0, dDH = ng == 2 ? k[1].DH - k[0].DH : 0;
@@ -259,8 +261,9 @@ int stacks_backward(hipStream_t st, const Sz& s, const WS& w, const psvae_batch&
             FusedLayerBwdGroup fg[2];
             for (int q = 0; q < ng; ++q)
                 fg[q] = FusedLayerBwdGroup{k[q].Gr + (size_t)(l + 1) * nH, k[q].Hid + (size_t)l * nH, k[q].w2tp, k[q].w1tp,
-                                           k[q].DH + (size_t)l * nH, k[q].DA + (size_t)l * nH};
-            PSVAE_TRY(gine_layer_bwd(st, fg, ng, n, H));
+                                           k[q].DH + (size_t)l * nH, k[q].DA + (size_t)l * nH,
+                                           (top_from_pool && l == t - 1 && dpool && dpool[q]) ? dpool[q] + (size_t)(t - 1) * H : nullptr};
+            PSVAE_TRY(gine_layer_bwd(st, fg, ng, n, H, b.node_graph, t * H));
         } else {
         GemmDesc d2;  // dHid_l = (G_{l+1} W2) * (Hid_l > 0)
         d2.A = k[0].Gr + (size_t)(l + 1) * nH; d2.lda = H; d2.B = k[0].w2; d2.ldb = H; d2.b_t = true;
@@ -686,7 +689,9 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     if (early2 && hipEventRecord(early2, s2) != hipSuccess) return (int)hipGetLastError();
     // --- GINE stacks: dL/dx_te of the encoder is the broadcast of the last pooled slice
     Stack k[2] = {enc_stack(d, p, &g, b, w), dec_stack(d, p, &g, b, w)};
-    if (!dec_only) {
+    // (with the cut-operand fused backward the top layer's launch forms the broadcast itself: one launch fewer on the chain)
+    const bool top_from_pool = !dec_only && fused_gine && gine_layer_split(s.H);
+    if (!dec_only && !top_from_pool) {
         AggBwdGroup top{nullptr, nullptr, w.GE + (size_t)s.te * nH, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f,
                         w.dpooled + (size_t)(s.te - 1) * s.H, 0, nullptr};
         PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
@@ -696,9 +701,9 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     if (dec_only) {
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1, 1));
     } else if (s.te == s.td) {
-        PSVAE_TRY(stacks_backward(st, s, w, b, k, 2, dpool, 0, 0));
+        PSVAE_TRY(stacks_backward(st, s, w, b, k, 2, dpool, 0, 0, top_from_pool));
     } else {
-        PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0, 0));
+        PSVAE_TRY(stacks_backward(st, s, w, b, &k[0], 1, &dpool[0], 0, 0, top_from_pool));
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1, 1));
     }
     // weight gradients of the shared GINE MLPs (sum over the t applications): encoder on lane 1,
