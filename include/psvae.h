@@ -72,8 +72,6 @@ int psvae_abi_version(void);
  *   gru_tiles      1 / 2 / 4: sequence tiles a workgroup of the multi-CU recurrence steps together
  *   gru_spin_ticks bound of a wait inside the multi-CU recurrence in ticks of 10 ns (default 2 s); 0: give up at
  *                  once, which exercises the redo on the single-CU kernels
- *   agg_items      1 / 2: items (node, channel chunk) a thread of the stand-alone aggregation kernels keeps in each
- *                  stage of its load pipeline
  * psvae_option_set / _get return PSVAE_E_SHAPE for an unknown name; psvae_option_name(i) enumerates the names
  * (NULL past the last). */
 int psvae_option_set(const char* name, int value);

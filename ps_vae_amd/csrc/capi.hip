@@ -26,7 +26,7 @@ extern "C" int psvae_abi_version(void) { return PSVAE_ABI_VERSION; }
 // ---- kernel-selection options: one table, filled from the environment (PSVAE_<NAME>) the first time it is read
 namespace {
 const char* const option_names[OPT_COUNT] = {"streams", "fused_layer", "fused_bwd", "fused_scorer", "split_bf16", "split_rows",
-                                             "split_gemm", "wide_gemm", "gru_multi_cu", "gru_tiles", "gru_spin_ticks", "agg_items"};
+                                             "split_gemm", "wide_gemm", "gru_multi_cu", "gru_tiles", "gru_spin_ticks"};
 int option_values[OPT_COUNT];
 std::once_flag option_once;
 

@@ -94,19 +94,7 @@ __device__ __forceinline__ float4 agg_msg4(float4 acc, const float* tab, int H, 
     return acc;
 }
 
-// One item of a thread's walk: node i, first channel c of its chunk, CSR bounds of the node's row.
-struct AggItem { int i, c, e0, e1; };
-__device__ __forceinline__ AggItem agg_item(const int32_t* __restrict__ rowptr, unsigned t, unsigned total, unsigned H4) {
-    t = min(t, total - 1);
-    AggItem r;
-    r.i = (int)(t / H4); r.c = (int)(t - (unsigned)r.i * H4) * 4;
-    r.e0 = ldi(rowptr, r.i); r.e1 = ldi(rowptr, r.i + 1);
-    return r;
-}
-
-// U = items a thread keeps in each pipeline stage (the items of one iteration lie one window apart): with 2, a wave
-// has twice the bytes in flight per round trip, which is what a launch that loops over many windows is short of.
-template <bool STREAM, int U>
+template <bool STREAM>
 __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) float etab_lds[];
     const AggGroup& g = a.g[blockIdx.y];
@@ -128,48 +116,38 @@ __global__ __launch_bounds__(256) void gine_agg_fwd_kernel(const AggArgs a) {
     const int32_t* __restrict__ etype = E > 0 ? g.etype : g.rowptr;
     const float* __restrict__ x = g.x;
     const unsigned ldxb = (unsigned)a.ldx * 4u, ldob = (unsigned)a.ldo * 4u;
-    // pipeline fill: bounds of the items of iterations 0 and 1, indices of iteration 0
-    AggItem A[U], B[U];
-    AggIdx qA[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { A[u] = agg_item(g.rowptr, tfirst + u * stride, total, H4); B[u] = agg_item(g.rowptr, tfirst + (U + u) * stride, total, H4); }
-#pragma unroll
-    for (int u = 0; u < U; ++u) qA[u] = agg_load_idx(col, etype, A[u].e0, A[u].e1, emax);
+    // pipeline fill: bounds of items 0 and 1, indices of item 0
+    int iA = (int)(tfirst / H4), cA = (int)(tfirst - (unsigned)iA * H4) * 4;
+    int eA0 = ldi(g.rowptr, iA), eA1 = ldi(g.rowptr, iA + 1);
+    const unsigned tB = min(tfirst + stride, total - 1);
+    int iB = (int)(tB / H4), cB = (int)(tB - (unsigned)iB * H4) * 4;
+    int eB0 = ldi(g.rowptr, iB), eB1 = ldi(g.rowptr, iB + 1);
+    AggIdx qA = agg_load_idx(col, etype, eA0, eA1, emax);
     // the edge table is staged while those index loads are in flight (a short launch is a chain of latencies)
     for (int k = threadIdx.x; k < H; k += blockDim.x) etab_lds[4 * H + k] = -INFINITY;   // row of the "no edge" type
     stage_edge_tab(etab_lds, g.edge_w, g.edge_b, H);
     if (!active) return;
-    for (unsigned t = tfirst; t < total; t += U * stride) {
-        // stage 3 of the items A: their own rows and four neighbour rows each
-        float4 xi[U], x0[U], x1[U], x2[U], x3[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            xi[u] = ld4r(x, A[u].i, ldxb, A[u].c);
-            x0[u] = ld4r(x, qA[u].j0, ldxb, A[u].c); x1[u] = ld4r(x, qA[u].j1, ldxb, A[u].c);
-            x2[u] = ld4r(x, qA[u].j2, ldxb, A[u].c); x3[u] = ld4r(x, qA[u].j3, ldxb, A[u].c);
+    for (unsigned t = tfirst; t < total; t += stride) {
+        // stage 3 of item A: its own row and four neighbour rows
+        const float4 xi = ld4r(x, iA, ldxb, cA);
+        const float4 x0 = ld4r(x, qA.j0, ldxb, cA), x1 = ld4r(x, qA.j1, ldxb, cA);
+        const float4 x2 = ld4r(x, qA.j2, ldxb, cA), x3 = ld4r(x, qA.j3, ldxb, cA);
+        // stage 2 of item B, stage 1 of item C
+        const AggIdx qB = agg_load_idx(col, etype, eB0, eB1, emax);
+        const unsigned tC = min(t + 2 * stride, total - 1);
+        const int iC = (int)(tC / H4), cC = (int)(tC - (unsigned)iC * H4) * 4;
+        const int eC0 = ldi(g.rowptr, iC), eC1 = ldi(g.rowptr, iC + 1);
+        float4 acc = agg_msg4(make_float4(0.f, 0.f, 0.f, 0.f), etab_lds, H, cA, qA, x0, x1, x2, x3);
+        for (int e = eA0 + 4; e < eA1; e += 4) {   // the rare row with more than four edges
+            const AggIdx q = agg_load_idx(col, etype, e, eA1, emax);
+            const float4 y0 = ld4r(x, q.j0, ldxb, cA), y1 = ld4r(x, q.j1, ldxb, cA);
+            const float4 y2 = ld4r(x, q.j2, ldxb, cA), y3 = ld4r(x, q.j3, ldxb, cA);
+            acc = agg_msg4(acc, etab_lds, H, cA, q, y0, y1, y2, y3);
         }
-        // stage 2 of the items B, stage 1 of the items C
-        AggIdx qB[U];
-        AggItem C[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) qB[u] = agg_load_idx(col, etype, B[u].e0, B[u].e1, emax);
-#pragma unroll
-        for (int u = 0; u < U; ++u) C[u] = agg_item(g.rowptr, t + (2 * U + u) * stride, total, H4);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float4 acc = agg_msg4(make_float4(0.f, 0.f, 0.f, 0.f), etab_lds, H, A[u].c, qA[u], x0[u], x1[u], x2[u], x3[u]);
-            for (int e = A[u].e0 + 4; e < A[u].e1; e += 4) {   // the rare row with more than four edges
-                const AggIdx q = agg_load_idx(col, etype, e, A[u].e1, emax);
-                const float4 y0 = ld4r(x, q.j0, ldxb, A[u].c), y1 = ld4r(x, q.j1, ldxb, A[u].c);
-                const float4 y2 = ld4r(x, q.j2, ldxb, A[u].c), y3 = ld4r(x, q.j3, ldxb, A[u].c);
-                acc = agg_msg4(acc, etab_lds, H, A[u].c, q, y0, y1, y2, y3);
-            }
-            if (u == 0 || t + u * stride < total)
-                st4r<STREAM>(g.out, A[u].i, ldob, A[u].c, make_float4(acc.x + g.ope * xi[u].x, acc.y + g.ope * xi[u].y,
-                                                                      acc.z + g.ope * xi[u].z, acc.w + g.ope * xi[u].w));
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { A[u] = B[u]; qA[u] = qB[u]; B[u] = C[u]; }
+        st4r<STREAM>(g.out, iA, ldob, cA,
+                     make_float4(acc.x + g.ope * xi.x, acc.y + g.ope * xi.y, acc.z + g.ope * xi.z, acc.w + g.ope * xi.w));
+        iA = iB; cA = cB; eA0 = eB0; eA1 = eB1; qA = qB;
+        iB = iC; cB = cC; eB0 = eC0; eB1 = eC1;
     }
 }
 
@@ -576,17 +554,8 @@ int gine_agg_fwd(hipStream_t s, const AggGroup* g, int ngroups, int ldx, int ldo
     double bytes = 0;
     for (int k = 0; k < ngroups; ++k) bytes += 2.0 * n * 4 * H + 5.0 * g[k].E + 4.0 * (n + 1);
     ProfScope prof(s, KC_AGG_FWD, bytes);
-    // two items per stage only where a thread has several windows to walk
-    const int want = opt(OPT_AGG_ITEMS);
-    const bool two = want == 2 || (want != 1 && blocks > 2 * AGG_FWD_MAX_BLOCKS);
-    if (two && 3LL * 2 * grid.x * 256 + items >= (1LL << 31)) return PSVAE_E_SHAPE;
-    if (a.stream_out) {
-        if (two) hipLaunchKernelGGL((gine_agg_fwd_kernel<true, 2>), grid, dim3(256), (size_t)20 * H, s, a);
-        else hipLaunchKernelGGL((gine_agg_fwd_kernel<true, 1>), grid, dim3(256), (size_t)20 * H, s, a);
-    } else {
-        if (two) hipLaunchKernelGGL((gine_agg_fwd_kernel<false, 2>), grid, dim3(256), (size_t)20 * H, s, a);
-        else hipLaunchKernelGGL((gine_agg_fwd_kernel<false, 1>), grid, dim3(256), (size_t)20 * H, s, a);
-    }
+    if (a.stream_out) hipLaunchKernelGGL(gine_agg_fwd_kernel<true>, grid, dim3(256), (size_t)20 * H, s, a);
+    else hipLaunchKernelGGL(gine_agg_fwd_kernel<false>, grid, dim3(256), (size_t)20 * H, s, a);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

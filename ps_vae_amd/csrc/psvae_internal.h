@@ -35,7 +35,6 @@ enum Option {
     OPT_GRU_MULTI_CU,    // 0 / 1: single-CU / multi-CU recurrence
     OPT_GRU_TILES,       // 1 / 2 / 4 sequence tiles per workgroup of the multi-CU recurrence
     OPT_GRU_SPIN_TICKS,  // bound of a multi-CU recurrence wait in 10 ns ticks; 0: give up at once (tests the redo)
-    OPT_AGG_ITEMS,       // 1 / 2 items per pipeline stage of the aggregation kernels
     OPT_COUNT
 };
 int opt(int which);

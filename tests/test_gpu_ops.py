@@ -120,19 +120,7 @@ def _random_graph(n, E, seed):
 @pytest.mark.parametrize('n,E,H', [(500, 1100, 300), (64, 0, 20), (1, 3, 8), (2000, 9000, 512),
                                    # outputs beyond 16 MB: the kernels write them with non-temporal stores
                                    (16001, 40000, 300), (14000, 60000, 320), (24000, 0, 200), (70000, 90000, 64)])
-@pytest.mark.parametrize('items', [-1, 1, 2])
-def test_gine_aggregate_forward_backward(n, E, H, items):
-    """`items`: nodes / channel chunks a thread keeps in each stage of its load pipeline (-1: the library's choice, which
-    is 2 for the launches that loop); the sums keep edge order either way."""
-    from ps_vae_amd import _lib, ops
-    old = _lib.set_option('agg_items', items)
-    try:
-        _aggregate_case(n, E, H)
-    finally:
-        _lib.set_option('agg_items', old)
-
-
-def _aggregate_case(n, E, H):
+def test_gine_aggregate_forward_backward(n, E, H):
     from ps_vae_amd import ops
     ei, et = _random_graph(n, E, seed=n)
     x, ew, eb = _rand(n, H, seed=1), _rand(H, 4, seed=2), _rand(H, seed=3, scale=0.1)
