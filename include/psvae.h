@@ -409,6 +409,14 @@ int psvae_gru_forward(const float* gi, const float* h0, const float* whh, const 
 int psvae_gru_backward(const float* dhseq, const float* hprev, const float* gates, const float* whh,
                        float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exchange,
                        size_t exchange_bytes, void* stream);
+/* psvae_gru_forward on the multi-CU kernel with time stamps, for profiling (no counterpart in the reference): thread 0
+ * of the first workgroup writes the GPU's 100 MHz wall clock to stamps[t][0..3] (device memory, T x 4 uint64) at the
+ * top of time step t, when the operands of h_t have arrived from the other workgroups, after the K-split partial sums
+ * went through LDS, and when the gates are done and h_{t+1} is published.  Outputs as psvae_gru_forward.  Only the
+ * kernel form taken for R <= 208 and one sequence tile per workgroup (PSVAE_E_SHAPE otherwise). */
+int psvae_gru_forward_stamped(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
+                              float* hprev, float* gates, int B, int T, int R, void* exchange, size_t exchange_bytes,
+                              uint64_t* stamps, void* stream);
 /* CrossEntropyLoss rows (ignore_index): row_loss, lse per row. src/modules/vae_piece_decoder.py:53-54 */
 int psvae_softmax_ce_forward(const float* logits, int ld, const int32_t* target, int target_stride,
                              int target_offset, int rows_per_group, int rows, int classes, int ignore_index,

@@ -154,6 +154,7 @@ def lib():
     L.psvae_gru_exchange_bytes.restype = C.c_size_t
     L.psvae_gru_exchange_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     L.psvae_gru_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    L.psvae_gru_forward_stamped.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp, vp]
     L.psvae_gru_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.psvae_softmax_ce_forward.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.psvae_collate_pairs.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp, i64, P(i64), vp, P(i64),
@@ -192,7 +193,7 @@ EXPORTS = (
     'psvae_noalloc_scratch_bytes', 'psvae_linear_backward_weight_noalloc',
     'psvae_gine_aggregate_forward', 'psvae_scorer_scratch_bytes', 'psvae_scorer_forward', 'psvae_gine_layer_scratch_bytes', 'psvae_gine_layer_forward', 'psvae_gine_aggregate_backward', 'psvae_gine_edge_grad_scratch',
     'psvae_segment_pool_forward',
-    'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs', 'psvae_gather_molecules',
+    'psvae_gru_exchange_bytes', 'psvae_gru_forward', 'psvae_gru_forward_stamped', 'psvae_gru_backward', 'psvae_softmax_ce_forward', 'psvae_collate_pairs', 'psvae_gather_molecules',
     'psvae_pack_bound', 'psvae_pack_batch', 'psvae_collate_device_layout', 'psvae_collate_device_scratch_bytes',
     'psvae_collate_device', 'psvae_profile_enable', 'psvae_profile_num_classes',
     'psvae_profile_class_name', 'psvae_profile_collect', 'psvae_profile_event_overhead_ms')

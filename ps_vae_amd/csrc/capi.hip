@@ -232,6 +232,15 @@ extern "C" int psvae_gru_forward(const float* gi, const float* h0, const float* 
     return gru_fwd((hipStream_t)stream, gi, h0, whh, bhh, hseq, hprev, gates, B, T, R, exchange, exchange_bytes);
 }
 
+extern "C" int psvae_gru_forward_stamped(const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
+                                         float* hprev, float* gates, int B, int T, int R, void* exchange,
+                                         size_t exchange_bytes, uint64_t* stamps, void* stream) {
+    if (!gi || !h0 || !whh || !bhh || !hseq || !hprev || !gates || !exchange || !stamps) return PSVAE_E_NULL;
+    if (B < 0 || T < 0 || R < 4) return PSVAE_E_SHAPE;
+    return gru_fwd_stamped((hipStream_t)stream, gi, h0, whh, bhh, hseq, hprev, gates, B, T, R, exchange, exchange_bytes,
+                           (unsigned long long*)stamps);
+}
+
 extern "C" int psvae_gru_backward(const float* dhseq, const float* hprev, const float* gates, const float* whh,
                                   float* dgi, float* dgh, float* dh0, int B, int T, int R, void* exchange,
                                   size_t exchange_bytes, void* stream) {

@@ -264,12 +264,17 @@ __device__ __forceinline__ bool sweep(gu64* first, long long stride, int count, 
 // j0+(l&15)) of every tile for the gate arithmetic = register w of lane l in the MFMA output layout, so the
 // cross-wave K reduction reads LDS without bank conflicts.
 // Exchange buffer: [parity][sequence tile][k][16 rows] words; h_t carries tag t.
-template <int KSW, int RB>
+// STAMP: thread 0 of workgroup (0, 0) writes the 100 MHz wall clock to stamps[t][0..3] at four points of every time
+// step (top of the step, operands of h_t arrived, K-split partial sums exchanged through LDS, gates done and h_{t+1}
+// published) - the instrumented variant behind psvae_gru_forward_stamped.
+template <int KSW, int RB, bool STAMP = false>
 __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
                                                            const float* __restrict__ whh, const float* __restrict__ bhh,
                                                            float* __restrict__ hseq, float* __restrict__ hprev,
                                                            float* __restrict__ gates, unsigned long long* exch_,
-                                                           int B, int T, int R, int n_st, unsigned long long spin_limit) {
+                                                           int B, int T, int R, int n_st, unsigned long long spin_limit,
+                                                           unsigned long long* stamps = nullptr) {
+    const bool stamper = STAMP && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0;
     __shared__ float red[2][RB][4][3][4][64];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
             hp[rb] = eok[rb] ? v : 0.f;
         }
         for (int t = 0; t < T; ++t) {
+            if (stamper) stamps[4 * t] = wall_clock64();
             float gir[RB], giz[RB], gin[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
                 gu64* first = exch + ((long long)((t & 1) * n_st + st0) * R + 4 * wave + kq) * 16 + j;
                 if (!sweep<KSW, RB>(first, 16 * 16, cnt, (long long)R * 16, ntl, (unsigned)t, a, giveup, spin_limit, lane)) s_fail = 1;
             }
+            if (stamper) stamps[4 * t + 1] = wall_clock64();
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 floatx4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
@@ -351,6 +358,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
             }
             __syncthreads();
             if (s_fail) { dead = true; break; }
+            if (stamper) stamps[4 * t + 2] = wall_clock64();
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 float(*rd)[3][4][64] = red[t & 1][rb];
@@ -373,6 +381,7 @@ __global__ __launch_bounds__(256) void gru_fwd_coop_kernel(const float* __restri
                 }
                 hp[rb] = hn;
             }
+            if (stamper) stamps[4 * t + 3] = wall_clock64();
         }
         __syncthreads();   // the next sequence group starts over on red[0]
     }
@@ -582,6 +591,23 @@ int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, c
     ProfScope prof(s, KC_GRU_FWD, coop ? 0.0 : 2.0 * B * T * 3 * R * R);
     hipLaunchKernelGGL(gru_fwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(64 * nwaves), lds, s, gi, h0, whh, bhh, hseq,
                        hprev, gates, B, T, R, run_if, redone);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// The multi-CU forward recurrence with time stamps (see gru_fwd_coop_kernel<.., STAMP>): only the form the library
+// takes for rows of up to 208 units and batches that step one sequence tile per workgroup.
+int gru_fwd_stamped(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
+                    float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, unsigned long long* stamps) {
+    if (B <= 0 || T <= 0 || !stamps) return PSVAE_E_SHAPE;
+    if (R % 4 || !aligned16(whh)) return PSVAE_E_ALIGN;
+    const int ntiles = ((R + 15) & ~15) / 16, n_st = (B + ROWS - 1) / ROWS;
+    if (!coop_ok(R, exch, exch_bytes, B, T) || (R >> 2) > 52 || coop_tiles_per_group(ntiles, n_st, 4) != 1) return PSVAE_E_SHAPE;
+    hipError_t e = hipMemsetAsync(exch, 0, gru_exchange_bytes(B, T, R), s);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid(ntiles, coop_slots(ntiles, n_st));
+    hipLaunchKernelGGL((gru_fwd_coop_kernel<13, 1, true>), grid, dim3(256), 0, s, gi, h0, whh, bhh, hseq, hprev, gates,
+                       (unsigned long long*)exch, B, T, R, n_st, spin_limit(), stamps);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

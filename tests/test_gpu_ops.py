@@ -140,6 +140,37 @@ def test_gine_aggregate_forward_backward(n, E, H):
     check_close(ebg.grad, ebr.grad if E else torch.zeros_like(eb), 'd edge_b')
 
 
+def test_gru_forward_stamped_is_the_same_recurrence():
+    """The instrumented multi-CU forward kernel writes the same bits as psvae_gru_forward and four rising clock values
+    per time step; shapes outside its one kernel form are refused."""
+    from ps_vae_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, T, R = 100, 7, 200
+    gi, h0 = _rand(B, T, 3 * R, seed=1).to(dev()), _rand(B, R, seed=2).to(dev())
+    whh, bhh = _rand(3 * R, R, seed=3, scale=R ** -0.5).to(dev()), _rand(3 * R, seed=4).to(dev())
+    nx = L.psvae_gru_exchange_bytes(B, T, R)
+    exch = torch.zeros(nx // 8 + 1, dtype=torch.int64, device=dev())
+    outs = []
+    for stamped in (False, True):
+        hseq, hprev = torch.empty(B, T, R, device=dev()), torch.empty(B, T, R, device=dev())
+        gates = torch.empty(B, T, 4 * R, device=dev())
+        stamps = torch.zeros(T, 4, dtype=torch.int64, device=dev())
+        args = (gi.data_ptr(), h0.data_ptr(), whh.data_ptr(), bhh.data_ptr(), hseq.data_ptr(), hprev.data_ptr(), gates.data_ptr(),
+                B, T, R, exch.data_ptr(), nx)
+        if stamped:
+            _lib.check(L.psvae_gru_forward_stamped(*args, stamps.data_ptr(), st))
+        else:
+            _lib.check(L.psvae_gru_forward(*args, st))
+        torch.cuda.synchronize()
+        outs.append((hseq, hprev, gates))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    flat = stamps.cpu().reshape(-1)
+    assert bool((flat[1:] >= flat[:-1]).all()) and int(flat[-1] - flat[0]) > 0
+    assert L.psvae_gru_forward_stamped(*args[:9], 256, exch.data_ptr(), nx, stamps.data_ptr(), st) == -2      # PSVAE_E_SHAPE
+
+
 def test_segment_pool_forward_backward():
     from ps_vae_amd import ops
     lens = torch.tensor([3, 1, 7, 38, 12, 1])
