@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 5
+#define PSVAE_ABI_VERSION 6
 
 enum {
     PSVAE_OK = 0,
@@ -215,7 +215,8 @@ typedef struct psvae_adam {
     float *params, *grads, *exp_avg, *exp_avg_sq;    /* flat fp32 buffers of `count` elements */
     int64_t count;
     float* partials;                                  /* psvae_adam_partials(count) floats */
-    float max_norm, lr, beta1, beta2, eps, bias1, bias2;
+    float max_norm;
+    double lr, beta1, beta2, eps, bias1, bias2;       /* as psvae_clip_adam takes them */
     float* grad_norm_out;                             /* device, may be NULL */
 } psvae_adam;
 int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
@@ -282,11 +283,13 @@ int psvae_normal_rows(uint64_t seed, uint64_t draw, int64_t first_row, int rows,
 /* ---- optimiser: clip_grad_norm_(10) + Adam (src/train.py:47; ps_vae_model.py:123-127)
  * over flat fp32 buffers of `count` elements.  `partials` is scratch of
  * psvae_adam_partials(count) floats; grad_norm_out (device, may be NULL) gets
- * the pre-clip L2 norm.  bias1/bias2 = 1-beta1^t, 1-beta2^t. */
+ * the pre-clip L2 norm.  bias1/bias2 = 1-beta1^t, 1-beta2^t.  The hyper-parameters are doubles, as torch holds
+ * them: 1 - beta, lr / bias1 and sqrt(bias2) are formed in double and rounded to fp32 once, like torch.optim.Adam's
+ * scalars (1.f - 0.999f is 1.3e-5 away from 0.001, enough to show in a loss curve after one step). */
 size_t psvae_adam_partials(int64_t count);
 int psvae_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
-                    float* partials, float max_norm, float lr, float beta1, float beta2, float adam_eps,
-                    float bias1, float bias2, float* grad_norm_out, void* stream);
+                    float* partials, float max_norm, double lr, double beta1, double beta2, double adam_eps,
+                    double bias1, double bias2, float* grad_norm_out, void* stream);
 
 /* ---- opt-in launch timer (benchmarking aid; no counterpart in the reference) ----
  * While enabled, every kernel launch of the library is bracketed by hipEvents on

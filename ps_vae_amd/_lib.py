@@ -74,7 +74,7 @@ BLOB_FIELDS = BATCH_PTRS
 
 class Adam(C.Structure):
     _fields_ = ([(k, vp) for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq')] + [('count', i64), ('partials', vp)] +
-                [(k, f32) for k in ('max_norm', 'lr', 'beta1', 'beta2', 'eps', 'bias1', 'bias2')] + [('grad_norm_out', vp)])
+                [('max_norm', f32)] + [(k, C.c_double) for k in ('lr', 'beta1', 'beta2', 'eps', 'bias1', 'bias2')] + [('grad_norm_out', vp)])
 
 
 class Batch(C.Structure):
@@ -127,7 +127,7 @@ def lib():
     L.psvae_normal_rows.argtypes = [C.c_uint64, C.c_uint64, i64, C.c_int, C.c_int, vp, vp]
     L.psvae_adam_partials.restype = sz
     L.psvae_adam_partials.argtypes = [i64]
-    L.psvae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]
+    L.psvae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, f32] + [C.c_double] * 6 + [vp, vp]
     L.psvae_linear_scratch_bytes.restype = sz
     L.psvae_linear_scratch_bytes.argtypes = [C.c_int] * 4
     L.psvae_linear_forward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, vp]
@@ -178,7 +178,7 @@ def lib():
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
     L.psvae_profile_event_overhead_ms.restype = C.c_double
     L.psvae_profile_event_overhead_ms.argtypes = [vp]
-    if L.psvae_abi_version() != 5:
+    if L.psvae_abi_version() != 6:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
     return L

@@ -72,8 +72,8 @@ extern "C" int psvae_option_get(const char* name, int* value) {
 extern "C" const char* psvae_option_name(int index) { return index >= 0 && index < OPT_COUNT ? option_names[index] : nullptr; }
 
 extern "C" int psvae_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
-                               float* partials, float max_norm, float lr, float beta1, float beta2, float adam_eps,
-                               float bias1, float bias2, float* grad_norm_out, void* stream) {
+                               float* partials, float max_norm, double lr, double beta1, double beta2, double adam_eps,
+                               double bias1, double bias2, float* grad_norm_out, void* stream) {
     return clip_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, count, partials, max_norm, lr, beta1, beta2,
                      adam_eps, bias1, bias2, grad_norm_out);
 }

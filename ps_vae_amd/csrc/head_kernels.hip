@@ -275,10 +275,12 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 }
 // Every block re-derives the clip coefficient from the same partials in the same
 // order, so all blocks agree bit for bit.  torch: coef = min(1, max_norm / (norm + 1e-6)).
+// The constants arrive as torch forms them: 1 - beta, lr / bias1 and sqrt(bias2) are worked out in double on the host
+// and rounded once (1.f - 0.999f is 1.3e-5 off 0.001, which would scale every update by 6e-6).
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long long count, const float* __restrict__ partials,
-                                                        float max_norm, float lr, float b1, float b2, float eps,
-                                                        float bias1, float bias2, float* __restrict__ norm_out) {
+                                                        float max_norm, float omb1, float b2, float omb2, float eps,
+                                                        float step, float sqrt_b2, float* __restrict__ norm_out) {
     __shared__ float sh[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < NORM_BLOCKS; i += 256) s += partials[i];
@@ -292,13 +294,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
     if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
     float coef = max_norm / (norm + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
-    const float step = lr / bias1, sqrt_b2 = sqrtf(bias2);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
-        const float gi = g[i] * coef;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float gi = g[i] * coef, m0 = m[i];
+        const float mi = m0 + omb1 * (gi - m0);                     // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (omb2 * gi) * gi;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         m[i] = mi; v[i] = vi; g[i] = gi;
-        p[i] -= step * (mi / (sqrtf(vi) / sqrt_b2 + eps));
+        p[i] += (-step * mi) / (sqrtf(vi) / sqrt_b2 + eps);         // param.addcdiv_(exp_avg, denom, value=-step_size)
     }
 }
 
@@ -626,7 +627,7 @@ int losses_finalize(hipStream_t s, const float* mse_row, int B, const float* pie
 size_t psvae_adam_partials(int64_t) { return NORM_BLOCKS; }
 
 int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count, float* partials,
-              float max_norm, float lr, float b1, float b2, float eps, float bias1, float bias2, float* norm_out) {
+              float max_norm, double lr, double b1, double b2, double eps, double bias1, double bias2, float* norm_out) {
     if (count <= 0) return 0;
     if (!p || !g || !m || !v || !partials) return PSVAE_E_NULL;
     { ProfScope prof(s, KC_ADAM, 4.0 * count);
@@ -636,8 +637,8 @@ int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t cou
     int blocks = (int)((count + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     { ProfScope prof(s, KC_ADAM, 28.0 * count);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, (long long)count, partials, max_norm, lr,
-                       b1, b2, eps, bias1, bias2, norm_out);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, (long long)count, partials, max_norm,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)(lr / bias1), (float)sqrt(bias2), norm_out);
     }
     PSVAE_LAUNCH_CHECK();
     return 0;

@@ -246,4 +246,4 @@ int gru_exchange_clear(hipStream_t s, void* exch, size_t exch_bytes, int B, int 
 
 // ------------------------------------------------------------ optimiser
 int clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count, float* partials,
-              float max_norm, float lr, float b1, float b2, float eps, float bias1, float bias2, float* norm_out);
+              float max_norm, double lr, double b1, double b2, double eps, double bias1, double bias2, float* norm_out);

@@ -280,6 +280,11 @@ def test_clip_adam_matches_torch():
                                      0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step, norm.data_ptr(), st))
         assert abs(float(norm) - float(want_norm)) <= 1e-5 * float(want_norm)
         check_close(p, pr.detach(), f'params after step {step}', rtol=1e-6, atol_scale=1e-6)
+        # the updates themselves (parameters minus start; ~ step * lr each): a constant formed in fp32, such as
+        # 1.f - 0.999f, scales all of them by some 1e-5 and shows in a loss curve after one step
+        upd, want_upd = (p.cpu() - p0).double(), (pr.detach() - p0).double()
+        assert float((upd - want_upd).abs().max()) <= 2e-6 * float(want_upd.abs().max()) + 6e-7, step      # (+ fp32 spacing of p)
+        assert abs(float(upd.abs().sum()) / float(want_upd.abs().sum()) - 1.0) <= 2e-6, step
 
 
 @pytest.mark.parametrize('n,E,H,save', [(2964, 6400, 300, True), (95, 160, 300, False), (33, 0, 64, True), (1, 0, 16, True),
