@@ -318,7 +318,8 @@ def bulk_message_passing(dev, graphs=4096, H=300, iters=40):
             'plain_copy_same_rows': {'us': tc * 1e6, 'achieved': 2.0 * n * 4 * H / tc / 1e9, 'frac': 2.0 * n * 4 * H / tc / 1e9 / HBM_PEAK_GBS}}
 
 
-PMC_FILE = 'profiles/r02_pmc_traffic.json'
+PMC_FILE = 'profiles/r03_pmc_traffic.json'
+FLAGS = None      # the parsed command line (set by main)
 
 
 def pmc_traffic(kernel_class, args, per_gpu):
@@ -406,16 +407,16 @@ class Leg:
         self.batches = [to_device(b, dev) for b in self.cpu_batches]
         model.flat_buffers()
         # Global loss denominators (non-pad tokens, pairs, graphs, properties summed over ranks) depend on the batch
-        # only.  PSVAE_BENCH_DENOMS selects how they are exchanged: "ride" (default) puts the NEXT batch's four local
+        # only.  --denoms selects how they are exchanged: "ride" (default) puts the NEXT batch's four local
         # counts behind the gradients, so that the last gradient message sums them too (no collective of their own);
         # "once" exchanges them once per collated batch before the timed region, as a loader that collates the
         # global batch would.
-        self.denoms_mode = os.environ.get('PSVAE_BENCH_DENOMS', 'ride') if dist_on else 'none'
+        self.denoms_mode = FLAGS.denoms if dist_on else 'none'
         tail = 4 if self.denoms_mode == 'ride' else 0
         self.message, self.tail = model.grad_message()
         if not dist_on:
             self.reducer = None
-        elif os.environ.get('PSVAE_DP_OVERLAP', '1') != '0':
+        elif FLAGS.dp_overlap:
             # three gradient messages in the order backward finishes them, the first two overlapped with it
             self.reducer = OverlappedReducer(model, always=True, tail=tail)
         else:
@@ -427,9 +428,9 @@ class Leg:
                 self.reducer.reduce_denoms(nb.local_denoms, out=nb.denoms)
             torch.cuda.synchronize()
         self.unit = model.unit_grad()       # loss.backward(unit): no fill / copy launches for the implicit gradient of 1
-        # PSVAE_BENCH_AUTOGRAD=1: the step through torch.autograd (training_step, backward, optimizer.step) instead of
+        # --autograd: the step through torch.autograd (training_step, backward, optimizer.step) instead of
         # PSVAEModel.train_step - same kernels, more host time
-        self.one_call = os.environ.get('PSVAE_BENCH_AUTOGRAD') != '1'
+        self.one_call = not FLAGS.autograd
 
     def step(self, i):
         model, n = self.model, self.n_distinct
@@ -480,7 +481,7 @@ class Leg:
         marks[0].record()
         for i in range(steps):
             loss = self.step(warmup + i)
-            if not os.environ.get('PSVAE_BENCH_NO_MARKS') or i == steps - 1:
+            if not FLAGS.no_marks or i == steps - 1:
                 marks[i + 1].record()       # per-step spread (median, p10, p90); the headline stays total time / steps
         host_enqueue_s = time.perf_counter() - t0      # how long the host needed to queue the work
         self.fence()
@@ -495,7 +496,7 @@ class Leg:
             # a rank's loss is its share of the global batch's loss (local sums over global counts)
             final = final if on_dev else final.cpu()
             torch.distributed.all_reduce(final, op=torch.distributed.ReduceOp.SUM)
-        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)) if not os.environ.get('PSVAE_BENCH_NO_MARKS') else [elapsed / steps * 1e3] * steps
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)) if not FLAGS.no_marks else [elapsed / steps * 1e3] * steps
         spread = {'median': per_step[len(per_step) // 2], 'p10': per_step[int(0.1 * (len(per_step) - 1))],
                   'p90': per_step[int(0.9 * (len(per_step) - 1))]}
         if self.model.recurrence_gave_up():
@@ -526,9 +527,20 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help='skip the encoder-only (4096 graphs per call) and stress '
                     '(60 atoms, hidden 512, 8 iterations, all pairs) configurations')
     ap.add_argument('--profile-steps', type=int, default=10)
+    ap.add_argument('--denoms', choices=('ride', 'once'), default='ride', help='data-parallel runs: the loss denominators '
+                    'ride behind the gradients of the previous step / are exchanged once per batch before the timed region')
+    ap.add_argument('--dp-overlap', type=int, default=1, help='0: one gradient message after backward instead of three '
+                    'overlapped with it')
+    ap.add_argument('--autograd', action='store_true', help='the step through torch.autograd instead of the one-call train_step')
+    ap.add_argument('--no-marks', action='store_true', help='no per-step event records inside the timed region')
+    ap.add_argument('--watchdog', type=int, default=0, help='seconds after which all stacks are dumped and the run ends')
+    ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank')
+    ap.add_argument('--late-streams', action='store_true', help='test switch: create the communicator before the side streams')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' rehearses the multi-rank "
                     "path on a box with fewer GPUs than ranks (ranks then share devices)")
     args = ap.parse_args()
+    global FLAGS
+    FLAGS = args
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # no launcher around us: start the ranks here, before anything in this process touches a GPU
         # (counted from the driver's topology files: this process must not initialise HIP; the ranks check again)
@@ -543,9 +555,9 @@ def main():
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
-    if os.environ.get('PSVAE_BENCH_WATCHDOG'):     # seconds; on expiry every thread's stack goes to stderr and the run ends
+    if args.watchdog > 0:     # seconds; on expiry every thread's stack goes to stderr and the run ends
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['PSVAE_BENCH_WATCHDOG']), exit=True)
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -563,14 +575,14 @@ def main():
         _lib.set_option('gru_multi_cu', 0)
     dev = torch.device('cuda', local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
-    # PSVAE_BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL path on one GPU)
-    dist_on = world > 1 or os.environ.get('PSVAE_BENCH_FORCE_DIST') == '1'
+    # --force-dist: run the collectives even with one rank (rehearses the RCCL path on one GPU)
+    dist_on = world > 1 or args.force_dist
     # the step's side streams are created before the communicator's, and checked to run beside the current stream
     def init_streams():
         torch.zeros(1, device=dev)
         torch.cuda.synchronize()
         _lib.check(_lib.lib().psvae_streams_init(torch.cuda.current_stream().cuda_stream), 'psvae_streams_init')
-    late_streams = os.environ.get('PSVAE_BENCH_LATE_STREAMS') == '1'     # test switch: communicator first
+    late_streams = args.late_streams     # test switch: communicator first
     if not late_streams:
         init_streams()
     if dist_on:

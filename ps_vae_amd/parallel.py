@@ -125,13 +125,12 @@ class OverlappedReducer(GradReducer):
 
 def make_reducer(model, group=None, always=False, overlap=None):
     """The reducer a data-parallel loop should use: three messages overlapped with backward when the model lives
-    on a GPU (`PSVAE_DP_OVERLAP=0` or `overlap=False` selects the single message after backward)."""
-    import os
+    on a GPU (`overlap=False` selects the single message after backward)."""
     model.flat_buffers()
     if dist.is_available() and dist.is_initialized():
         model.shard_rank = dist.get_rank(group)      # keys the epsilon rows of batches that carry no graph_base
     if overlap is None:
-        overlap = os.environ.get('PSVAE_DP_OVERLAP', '1') != '0'
+        overlap = True
     if overlap and model.flat_buffers()[1].is_cuda:
         return OverlappedReducer(model, group, always)
     return GradReducer([0, model._n_trained], group, always)

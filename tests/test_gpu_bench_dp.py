@@ -17,9 +17,9 @@ def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it and no WORLD_SIZE in the environment: the program
     itself starts the two rank processes; its standard output is rank 0's single result line, for the whole job."""
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200')
+    env.update(GLOO_SOCKET_IFNAME='lo')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--backend', 'gloo',
-           '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--config3-steps', '3']
+           '--watchdog', '200', '--no-configs', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--config3-steps', '3']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -36,10 +36,10 @@ def test_bench_starts_its_own_ranks():
 @pytest.mark.timeout(300)
 def test_bench_two_ranks_under_a_launcher():
     """The driver's form: torch.distributed.run starts the ranks, bench.py reads RANK / WORLD_SIZE."""
-    env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200')
+    env = dict(os.environ, GLOO_SOCKET_IFNAME='lo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--backend', 'gloo', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--scaling', 'strong',
+           '--backend', 'gloo', '--watchdog', '200', '--no-configs', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--scaling', 'strong',
            '--global-batch', '96', '--vocab', '500', '--config3-steps', '0']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -54,20 +54,19 @@ def test_bench_two_ranks_under_a_launcher():
 def test_bench_collectives_over_rccl_with_one_rank():
     """The RCCL code path (process group on the device, all-reduce of the flat gradient, look-ahead
     all-reduce of the denominators) with the one rank a single-GPU box allows."""
-    env = dict(os.environ, PSVAE_BENCH_FORCE_DIST='1', PSVAE_BENCH_WATCHDOG='200', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT='29537', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29537', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-bulk',
-           '--profile-steps', '1']
+           '--no-configs', '--force-dist', '--watchdog', '200', '--profile-steps', '1']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
     assert res['n_gpus'] == 1 and res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']
 
 
-def _run(env_extra, ranks, backend, port, extra=()):
-    env = dict(os.environ, GLOO_SOCKET_IFNAME='lo', PSVAE_BENCH_WATCHDOG='200', **env_extra)
+def _run(flags, ranks, backend, port, extra=()):
+    env = dict(os.environ, GLOO_SOCKET_IFNAME='lo')
     tail = [os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6', '--warmup', '2', '--backend', backend,
-            '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--config3-steps', '0'] + list(extra)
+            '--watchdog', '200', '--no-configs', '--no-cpu-baseline', '--no-bulk', '--profile-steps', '1', '--config3-steps', '0'] + list(flags) + list(extra)
     if ranks > 1:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
                '127.0.0.1', '--master-port', str(port)] + tail
@@ -85,15 +84,15 @@ def test_overlapped_gradient_reduce_gives_the_same_run():
     records: the default), must leave the run exactly where the single message after backward leaves it; and two
     ranks on the halves of a batch must end where one process ends on the whole batch (same graphs, same
     negative pairs, same epsilon per graph), up to the order of fp32 sums."""
-    early = _run({}, 2, 'gloo', 29543)
-    plain = _run({'PSVAE_DP_OVERLAP': '0'}, 2, 'gloo', 29541)
+    early = _run([], 2, 'gloo', 29543)
+    plain = _run(['--dp-overlap', '0'], 2, 'gloo', 29541)
     assert 'OverlappedReducer' in early['config']['grad_reduce'] and 'GradReducer' in plain['config']['grad_reduce']
     assert early['config']['final_loss'] == plain['config']['final_loss']
-    once = _run({'PSVAE_BENCH_DENOMS': 'once'}, 2, 'gloo', 29549)
+    once = _run(['--denoms', 'once'], 2, 'gloo', 29549)
     assert once['config']['final_loss'] == plain['config']['final_loss']
-    rccl = _run({'PSVAE_BENCH_FORCE_DIST': '1'}, 1, 'nccl', 29545)
-    single = _run({}, 1, 'nccl', 29547)
+    rccl = _run(['--force-dist'], 1, 'nccl', 29545)
+    single = _run([], 1, 'nccl', 29547)
     assert rccl['rccl_ranks'] == 1 and single['rccl_ranks'] == 0
     assert rccl['config']['final_loss'] == single['config']['final_loss']
-    whole = _run({}, 1, 'nccl', 29551, extra=['--batch-size', '256'])
+    whole = _run([], 1, 'nccl', 29551, extra=['--batch-size', '256'])
     assert abs(early['config']['final_loss'] - whole['config']['final_loss']) <= 2e-4 * abs(whole['config']['final_loss'])
