@@ -230,7 +230,9 @@ int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const p
  * onto a small number of hardware queues in creation order and streams that share a queue serialise, so a process
  * that also creates communicator (RCCL) or other library streams should call this once per device; otherwise
  * optional (the first step call creates the side streams without the check).  Synchronises `stream`.  Returns 0
- * also when the side streams are disabled (option streams = 0) or already exist. */
+ * also when the side streams are disabled (option streams = 0) or already exist.  Also looks up the device address
+ * of the static scratch array of psvae_linear_backward_weight_noalloc on this device, so that a caller who must not
+ * make runtime calls other than launches (HIP graph capture) can use that entry point from its first call on. */
 int psvae_streams_init(void* stream);
 /* Offsets (in floats) of named activations inside the workspace, for tests and
  * the module-level API.  Returns -1 for an unknown name. */

@@ -1124,6 +1124,13 @@ int noalloc_scratch(float** out) {
 
 extern "C" size_t psvae_noalloc_scratch_bytes(void) { return NOALLOC_SCRATCH_FLOATS * sizeof(float); }
 
+// Looks the current device's copy of the static array up now (psvae_streams_init calls this), so that the first call
+// of the no-allocation entry point on this device makes no runtime call but its launches.
+int noalloc_scratch_init() {
+    float* p = nullptr;
+    return noalloc_scratch(&p);
+}
+
 extern "C" int psvae_linear_backward_weight_noalloc(const float* dy, int lddy, int64_t seg_stride_dy, const float* x, int ldx,
                                                     int64_t seg_stride_x, int nseg, float* dw, float* db, int M, int N, int K,
                                                     void* stream) {

@@ -73,6 +73,7 @@ struct GemmDesc {
     float* scratch = nullptr; size_t scratch_floats = 0;
 };
 int gemm_f32(hipStream_t s, const GemmDesc& d);
+int noalloc_scratch_init();     // resolves the static scratch array of the no-allocation entry point on the current device
 size_t gemm_scratch_floats(int M, int N, int R, int nseg, bool sum_segments);
 
 // Linear-layer helpers on top of gemm_f32

@@ -369,6 +369,7 @@ Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
 // share a queue run one after the other; which queue a stream gets depends on every other stream the process
 // (communicator, libraries) has created before.
 extern "C" int psvae_streams_init(void* stream) {
+    PSVAE_TRY(noalloc_scratch_init());
     Lanes* L = get_lanes(true, (hipStream_t)stream);
     if (!L) return 0;       // lanes disabled (option streams = 0) or unavailable: every call stays on the caller's stream
     if (hipStreamSynchronize(L->s1) != hipSuccess || hipStreamSynchronize(L->s2) != hipSuccess)
