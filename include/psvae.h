@@ -15,13 +15,16 @@
  *  - The caller owns every buffer, including the workspace; the library
  *    allocates no device memory.  Its only state is, per device, two side
  *    streams and a set of events created on the first step call (see
- *    psvae_step_forward), so step calls on one device must not overlap: ONE
- *    caller per device at a time.  Two host threads, or two models on different
- *    streams, that call psvae_step_forward / _backward / _backward_signal for the
- *    same device concurrently would record and wait on the same events and share
- *    the same side streams, i.e. build wrong dependencies; serialise such callers
- *    (the other entry points have no such state).  Besides that the library holds,
- *    per device, one 32 MiB device array (psvae_linear_backward_weight_noalloc).
+ *    psvae_step_forward) and shared by all step calls on that device.  Host
+ *    threads that call psvae_step_forward / _backward / _backward_signal /
+ *    psvae_train_step for the same device at the same time are serialised by the
+ *    library (a mutex per device held while a call enqueues), and calls on
+ *    different streams get correct dependencies (every wait belongs to the record
+ *    made by the same call); what stays the caller's duty is memory: two calls
+ *    that share a workspace must be ordered on the GPU (same stream, or an
+ *    event).  The other entry points have no such state.  Besides that the
+ *    library holds, per device, one 32 MiB device array
+ *    (psvae_linear_backward_weight_noalloc).
  *  - Work is enqueued on the hipStream_t passed as `stream` (a void* here so the
  *    header needs no HIP include); no entry point synchronises the device.
  *  - Return value: 0 = success; negative = PSVAE_E_* argument error detected on

@@ -363,6 +363,19 @@ Lanes* get_lanes(bool probe = false, hipStream_t caller = nullptr) {
     }
     return lanes_per_device[dev];
 }
+// The lanes and their events are shared by every step call on a device: a call records an event and waits for it a few
+// lines later, so two host threads inside step calls for the same device at the same time would wait for each other's
+// records.  Each step entry point holds the device's mutex while it enqueues (uncontended: some 20 ns per call).
+std::mutex step_mu[65];
+struct StepLock {
+    std::unique_lock<std::mutex> held;
+    StepLock() {
+        int dev = 64;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 64;
+        held = std::unique_lock<std::mutex>(step_mu[dev]);
+    }
+};
+
 // Creates the calling device's lanes now instead of inside the first step call, and makes sure that they and
 // `stream` (the stream the step calls will be given) sit on different hardware queues.  HIP deals a process's
 // streams onto a few hardware queues (four by default) in the order they are created, and two streams that
@@ -461,6 +474,7 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     WS w;
     if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    StepLock one_enqueuer_per_device;
     Lanes* L = get_lanes();
     hipStream_t s1 = L ? L->s1 : st, s2 = L ? L->s2 : st;
     const size_t scf = w.scratch_floats;
@@ -548,6 +562,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     WS w;
     if (carve(s, (float*)workspace, &w, nullptr, nullptr) * sizeof(float) > workspace_bytes) return PSVAE_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    StepLock one_enqueuer_per_device;
     Lanes* L = get_lanes();
     hipStream_t s1 = L ? L->s1 : st, s2 = L ? L->s2 : st;
     const size_t scf = w.scratch_floats;

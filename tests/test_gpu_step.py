@@ -245,6 +245,47 @@ def test_train_step_entry_equals_the_three_calls():
         model.train_step(batch, None, eps=eps[0])
 
 
+def test_two_host_threads_step_on_one_device():
+    """Two host threads, each with a model, a stream and batches of its own, run optimiser steps on the same GPU at the
+    same time.  The step calls share the device's side streams and events; the library serialises the threads while a
+    call enqueues, so each model must end exactly where it ends when the two runs happen one after the other.  (A
+    smoke test of the threaded use: two Python threads overlap inside the library only now and then, so a pass does not
+    prove the absence of a race; the guarantee is the per-device mutex in the step entry points.)"""
+    import threading
+    from ps_vae_amd import synth
+    d, V, B, steps = O.default_dims(300), 300, 24, 40
+    tok0 = build(d, V)[1]
+    jobs = []
+    for t in range(2):
+        batches = [collate_both(synth.make_molecules(700 + 10 * t + i, 'zinc', V, B), tok0, V, 60 + i)[1] for i in range(2)]
+        eps = [torch.randn(B, d['latent'], generator=torch.Generator().manual_seed(90 + 10 * t + i)) for i in range(steps)]
+        jobs.append((batches, eps))
+
+    def run(job, out, slot, stream):
+        batches, eps = job
+        with torch.cuda.stream(stream):
+            model = build(d, V, seed=2021 + slot)[0]
+            opt = model.configure_optimizers()
+            for i in range(steps):
+                model.train_step(batches[i % 2], opt, eps=eps[i])
+                model.global_step += 1
+            stream.synchronize()
+            out[slot] = model.flat_buffers()[0].clone()
+
+    serial, threaded = [None, None], [None, None]
+    for t in range(2):
+        run(jobs[t], serial, t, torch.cuda.Stream())
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=run, args=(jobs[t], threaded, t, torch.cuda.Stream())) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    for t in range(2):
+        assert threaded[t] is not None and torch.equal(serial[t], threaded[t]), f'model of thread {t}'
+
+
 def test_module_level_encoder_matches_oracle():
     """Encoder.embed_node / embed_graph and Predictor through the single-operator API."""
     from ps_vae_amd import synth
