@@ -1081,6 +1081,18 @@ size_t fused_pack_floats(int N, int K) {
 // Do the fused GINE kernels run their products on the bf16 matrix instruction over three-way cut operands (fp32
 // accuracy, see above)?  Option split_bf16 = 0 keeps the fp32 instruction.  Whoever packs the weights for
 // gine_layer_fwd / gine_layer_bwd must ask this and set FusedPack::split accordingly.
+// Raises a kernel's dynamic-LDS limit when a launch needs more than was granted so far: once per kernel instantiation
+// and size instead of a runtime call in front of every launch (one process drives one GPU).
+template <auto Kernel>
+static int grant_lds(size_t lds) {
+    static size_t granted = 48 * 1024;
+    if (lds <= granted) return 0;
+    if (hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return (int)hipGetLastError();
+    granted = lds;
+    return 0;
+}
+
 bool gine_layer_split(int H) {
     return opt(OPT_SPLIT_BF16) != 0 && H >= 16 && H <= 512;
 }
@@ -1146,9 +1158,7 @@ int gine_layer_fwd(hipStream_t s, const FusedLayerGroup* grp, int ng, int ldx, i
     ProfScope prof(s, KC_GINE_LAYER, flops);
 #define FLS_LAUNCH2(CT_, RT_, SAVE_)                                                                                     \
     do {                                                                                                                 \
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_fwd_split_kernel<CT_, RT_, SAVE_>,            \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
-            return (int)hipGetLastError();                                                                               \
+        PSVAE_TRY((grant_lds<gine_layer_fwd_split_kernel<CT_, RT_, SAVE_>>(lds)));                                       \
         hipLaunchKernelGGL((gine_layer_fwd_split_kernel<CT_, RT_, SAVE_>), grid, dim3(FL_THREADS), lds, s, a);           \
     } while (0)
 #define FLS_LAUNCH(CT_)                                                                                                  \
@@ -1307,9 +1317,7 @@ int gine_layer_bwd(hipStream_t s, const FusedLayerBwdGroup* grp, int ng, int n, 
     ProfScope prof(s, KC_GINE_LAYER_BWD, 4.0 * n * H * H * ng);
 #define FLBS_LAUNCH2(CT_, RT_)                                                                                        \
     do {                                                                                                              \
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gine_layer_bwd_split_kernel<CT_, RT_>,                \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-            return (int)hipGetLastError();                                                                            \
+        PSVAE_TRY((grant_lds<gine_layer_bwd_split_kernel<CT_, RT_>>(lds)));                                           \
         hipLaunchKernelGGL((gine_layer_bwd_split_kernel<CT_, RT_>), grid, dim3(FL_THREADS), lds, s, a);               \
     } while (0)
 #define FLBS_LAUNCH(CT_) do { if (rows == 64) FLBS_LAUNCH2(CT_, 4); else FLBS_LAUNCH2(CT_, 2); } while (0)
