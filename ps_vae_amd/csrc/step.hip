@@ -463,9 +463,33 @@ extern "C" int64_t psvae_workspace_offset(const psvae_dims* dims, const psvae_ba
     return off;
 }
 
-extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
-                                  void* workspace, size_t workspace_bytes, const float* loss_weights, float* losses,
-                                  void* stream) {
+namespace {
+// The weights backward's fused kernels read, in their transposed role and the matrix cores' fragment order: the GINE
+// MLPs of the stacks that run the one-launch backward, the link scorer's where its one-launch backward runs.
+// `*any` tells whether anything was queued.
+int backward_packs(hipStream_t on, const psvae_dims& d, const psvae_params& p, const psvae_batch& b, const Sz& s, const WS& w, bool* any) {
+    const bool dec_only = b.conds != nullptr;
+    const bool fused_gine = fused_bwd_on(s.n, (dec_only || s.te != s.td) ? 1 : 2, s.H) && gine_layer_fused_supported(s.H, s.H, s.H);
+    if (fused_gine) {
+        const Stack kk[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
+        FusedPack pk[4];
+        int cnt = 0;
+        for (int q = dec_only ? 1 : 0; q < 2; ++q) {
+            pk[cnt++] = FusedPack{kk[q].w1, kk[q].w1tp, s.H, s.H, s.H, true, gine_layer_split(s.H)};
+            pk[cnt++] = FusedPack{kk[q].w2, kk[q].w2tp, s.H, s.H, s.H, true, gine_layer_split(s.H)};
+        }
+        PSVAE_TRY(fused_pack(on, pk, cnt));
+    }
+    const bool fused_scorer = fused_scorer_bwd_on(s.S, s.H) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
+    if (fused_scorer) PSVAE_TRY(scorer_pack_bwd(on, p.sc_w0, p.sc_w1, p.sc_w2, w.spack + scorer_pack_floats(s.H, s.Z), s.H, s.Z));
+    *any = fused_gine || fused_scorer;
+    return 0;
+}
+
+// `for_training` (psvae_train_step): backward follows inside the same library call, so its packed weights are laid out
+// here as well, beside the forward ones and off every dependent chain.
+int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
+                 size_t workspace_bytes, const float* loss_weights, float* losses, void* stream, bool for_training) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !losses) return PSVAE_E_NULL;
     if (!aligned16(workspace)) return PSVAE_E_ALIGN;
@@ -482,14 +506,15 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
     // lane 1 starts with the part of the piece branch that needs no latent: token embeddings and
     // the GRU input products for all steps (src/modules/vae_piece_decoder.py:82,87-89)
     if (L) PSVAE_TRY(hand_over(st, s1, L->ev[0]));
-    // lane 2 first lays the weights of the fused kernels out in the matrix cores' fragment order (GINE MLPs of both
-    // stacks, link scorer): off the dependent chain, which needs them only after the embeddings and node_trans
+    // lane 1 first lays the weights of the fused kernels out in the matrix cores' fragment order (GINE MLPs of both
+    // stacks, link scorer): off the dependent chain, which needs them only after the embeddings and node_trans.  (On
+    // lane 1, which has just been handed over to, rather than on lane 2: a hand-over - an event record plus a stream
+    // wait - costs the host 10-13 us, as much as four kernel launches.)
     const bool dec_only = b.conds != nullptr;
     const bool fused_gine = fused_layers_on() && gine_layer_fused_supported(s.H, s.H, s.H);
     const bool fused_scorer = fused_scorer_fwd_on(s.S, s.H) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     hipEvent_t packed = nullptr;
-    if (L && (fused_gine || fused_scorer)) {
-        PSVAE_TRY(hand_over(st, s2, L->ev[5]));
+    if (L && (fused_gine || fused_scorer || for_training)) {
         if (fused_gine) {
             const Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
             FusedPack pk[4];
@@ -498,13 +523,19 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
                 pk[cnt++] = FusedPack{k[q].w1, k[q].w1p, s.H, s.H, s.H, false, gine_layer_split(s.H)};
                 pk[cnt++] = FusedPack{k[q].w2, k[q].w2p, s.H, s.H, s.H, false, gine_layer_split(s.H)};
             }
-            PSVAE_TRY(fused_pack(s2, pk, cnt));
+            PSVAE_TRY(fused_pack(s1, pk, cnt));
         }
-        if (fused_scorer) PSVAE_TRY(scorer_pack(s2, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
-        if (hipEventRecord(L->ev[6], s2) != hipSuccess) return (int)hipGetLastError();
-        packed = L->ev[6];
-    } else if (fused_scorer) {
-        PSVAE_TRY(scorer_pack(st, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
+        if (fused_scorer) PSVAE_TRY(scorer_pack(s1, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
+        if (fused_gine || fused_scorer) {
+            if (hipEventRecord(L->ev[6], s1) != hipSuccess) return (int)hipGetLastError();
+            packed = L->ev[6];
+        }
+        bool any = false;
+        if (for_training) PSVAE_TRY(backward_packs(s1, d, p, b, s, w, &any));    // (reach backward through the join below)
+    } else {
+        if (fused_scorer) PSVAE_TRY(scorer_pack(st, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
+        bool any = false;
+        if (for_training) PSVAE_TRY(backward_packs(st, d, p, b, s, w, &any));
     }
     PSVAE_TRY(rows_gather(s1, b.pieces, 0, s.T, s.L, p.piece_emb, s.Dp, w.semb, s.BT));
     PSVAE_TRY(linear_fwd(s1, w.semb, s.Dp, p.gru_wih, p.gru_bih, w.gi, 3 * s.R, s.BT, 3 * s.R, s.Dp, 0, w.scratch1, scf));
@@ -547,14 +578,28 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
         PSVAE_TRY(fill_zero(s2, w.mse_row, s.B));   // no property head: its loss reads 0
     }
     if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[3])); PSVAE_TRY(hand_over(s2, st, L->ev[4])); }
+    // the recurrence's exchange buffer is left zeroed for backward's recurrence, behind the join: nothing waits for it
+    PSVAE_TRY(gru_exchange_clear(s1, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));
     // straight into the caller's buffer (a separate 24-byte copy would be one more dependent launch)
     return losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, losses);
 }
+}  // namespace
+
+extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
+                                  void* workspace, size_t workspace_bytes, const float* loss_weights, float* losses,
+                                  void* stream) {
+    return step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, false);
+}
 
 namespace {
+// `after_forward` (psvae_train_step): the forward pass of the same batch was queued by the same library call just before.
+// Its packed weights for backward are in place, and the lanes need no hand-over from the caller's stream to start:
+// what their first kernels read (logits, predictions, the loss gradients the caller prepared before the call) was
+// written on the lanes themselves or before the lanes last waited for the caller's stream.
 int step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
                   void* workspace, size_t workspace_bytes, const float* loss_weights,
-                  const float* loss_grads, const psvae_params* grads, void* stream, hipEvent_t early1, hipEvent_t early2) {
+                  const float* loss_grads, const psvae_params* grads, void* stream, hipEvent_t early1, hipEvent_t early2,
+                  bool after_forward = false) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !loss_grads || !grads) return PSVAE_E_NULL;
     const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_params& g = *grads; const psvae_batch& b = *batch;
@@ -572,38 +617,30 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     // upstream gradients of [pred, piece, edge, kl]: derived inside the kernels that use them
     const GScale gs{loss_grads, loss_weights ? loss_weights[0] : 0.f, loss_weights ? loss_weights[1] : 0.f,
                     loss_weights ? loss_weights[2] : 0.f};
-    if (L) { PSVAE_TRY(hand_over(st, s1, L->ev[0])); PSVAE_TRY(hand_over(st, s2, L->ev[1])); }
+    if (L && !after_forward) { PSVAE_TRY(hand_over(st, s1, L->ev[0])); PSVAE_TRY(hand_over(st, s2, L->ev[1])); }
     // lane 2 first: the GINE MLP weights in their transposed role, laid out for the fused backward kernel (the
     // dependent chain reaches the GINE stacks hundreds of microseconds later)
     const bool dec_only_ = b.conds != nullptr;
     const bool fused_gine = fused_bwd_on(s.n, (dec_only_ || s.te != s.td) ? 1 : 2, s.H) && gine_layer_fused_supported(s.H, s.H, s.H);
-    if (fused_gine) {
-        const Stack kk[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
-        FusedPack pk[4];
-        int cnt = 0;
-        for (int q = dec_only_ ? 1 : 0; q < 2; ++q) {
-            pk[cnt++] = FusedPack{kk[q].w1, kk[q].w1tp, s.H, s.H, s.H, true, gine_layer_split(s.H)};
-            pk[cnt++] = FusedPack{kk[q].w2, kk[q].w2tp, s.H, s.H, s.H, true, gine_layer_split(s.H)};
-        }
-        PSVAE_TRY(fused_pack(s2, pk, cnt));
-    }
     const bool fused_scorer = fused_scorer_bwd_on(s.S, s.H) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     float* spack_bwd = w.spack + scorer_pack_floats(s.H, s.Z);
-    if (fused_scorer) PSVAE_TRY(scorer_pack_bwd(s2, p.sc_w0, p.sc_w1, p.sc_w2, spack_bwd, s.H, s.Z));
-    if (L && (fused_gine || fused_scorer) && hipEventRecord(L->ev[15], s2) != hipSuccess) return (int)hipGetLastError();
-    // the recurrence's exchange buffer is zeroed on lane 2, off the piece branch's dependent chain
-    PSVAE_TRY(gru_exchange_clear(s2, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));
-    if (L && hipEventRecord(L->ev[14], s2) != hipSuccess) return (int)hipGetLastError();
+    bool packs_pending = false;      // the caller's stream has to wait for event 15 before it uses the packed weights
+    if (!after_forward) {
+        PSVAE_TRY(backward_packs(s2, d, p, b, s, w, &packs_pending));
+        if (L && packs_pending && hipEventRecord(L->ev[15], s2) != hipSuccess) return (int)hipGetLastError();
+    }
+    // (the recurrence's exchange buffer was zeroed by the forward call, behind its own recurrence, and backward's
+    //  recurrence zeroes it again behind itself: no launch in front of the recurrence, no hand-over for it)
     // --- lane 1: piece branch (cross-entropy, to_vocab, GRU, latent_to_rnn_hidden)
     PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
-    if (L && hipStreamWaitEvent(s1, L->ev[14], 0) != hipSuccess) return (int)hipGetLastError();
     PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     if ((long long)s.B * s.Z <= SMALL_LINEAR_OUTPUTS) PSVAE_TRY(small_linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z));
     else PSVAE_TRY(linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z, nullptr, 0, 0));
     // (dz_piece is what the caller's stream waits for in front of the latent head; the piece-embedding gradient the
     //  next product feeds is not needed before the embedding tables, at the end of the step)
     if (L && hipEventRecord(L->ev[2], s1) != hipSuccess) return (int)hipGetLastError();   // dz_piece ready
+    PSVAE_TRY(gru_exchange_clear(s1, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));      // clean for a second backward on this forward
     PSVAE_TRY(linear_bwd_x(s1, w.dgi, 3 * s.R, p.gru_wih, w.dsemb, s.Dp, s.BT, 3 * s.R, s.Dp, nullptr, 0, 0));
     if (L && hipEventRecord(L->ev[16], s1) != hipSuccess) return (int)hipGetLastError();  // dsemb ready
     PSVAE_TRY(linear_bwd_w(s1, w.logits, s.ldl, 0, w.hseq, s.R, 0, 1, g.vocab_w, g.vocab_b, s.BT, s.V2, s.R, sc1, scf));
@@ -636,25 +673,28 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
         if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
         PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
         PSVAE_TRY(linear_bwd_w(s2, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc2, scf));
-        if (L && hipStreamWaitEvent(st, L->ev[15], 0) != hipSuccess) return (int)hipGetLastError();
+        if (L && packs_pending && hipStreamWaitEvent(st, L->ev[15], 0) != hipSuccess) return (int)hipGetLastError();
         ScorerBwd sb{w.ds3, w.s2, w.s1, spack_bwd, w.ds2, w.ds1, w.dpin, s.S, s.H, s.Z};
         PSVAE_TRY(scorer_bwd_fused(st, sb));
         if (L) PSVAE_TRY(hand_over(st, s2, L->ev[5]));
         PSVAE_TRY(linear_bwd_w(s2, w.ds2, s.P2, 0, w.s1, s.P2, 0, 1, g.sc_w1, g.sc_b1, s.S, s.P2, s.P2, sc2, scf));
         PSVAE_TRY(linear_bwd_w(s2, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc2, scf));
     } else {
-    // (With few pairs the three weight gradients are queued behind the whole input-gradient chain instead of each
+    // (With few pairs the four weight gradients are queued behind the whole input-gradient chain instead of each
     //  behind its own link: the chain, which the caller's stream waits for, then runs beside fewer competing
-    //  workgroups, and three hand-overs go - +0.5 % at 128 graphs, -0.7 % at 256.)
-    const bool dw_late = s.S <= 6144;
-    if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
-    PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
+    //  workgroups, and three of four hand-overs go - +0.5 % at 128 graphs, -0.7 % at 256.)
+    const bool dw_late = s.S <= 6144 && L;
+    if (!dw_late) {
+        if (L) PSVAE_TRY(hand_over(st, s2, L->ev[4]));
+        PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
+    }
     if (!fused_pair_head) PSVAE_TRY(linear_bwd_x(st, w.slog, 4, p.sc_w3, w.ds3, s.P, s.S, 4, s.P, nullptr, 0, 0));
-    if (dw_late && L) {
+    if (dw_late) {
         PSVAE_TRY(linear_bwd_x(st, w.ds3, s.P, p.sc_w2, w.ds2, s.P2, s.S, s.P, s.P2, w.s2, s.P2, 0));
         PSVAE_TRY(linear_bwd_x(st, w.ds2, s.P2, p.sc_w1, w.ds1, s.P2, s.S, s.P2, s.P2, w.s1, s.P2, 0));
         PSVAE_TRY(linear_bwd_x(st, w.ds1, s.P2, p.sc_w0, w.dpin, s.P, s.S, s.P2, s.P, nullptr, 0, 0));
-        PSVAE_TRY(hand_over(st, s2, L->ev[7]));
+        PSVAE_TRY(hand_over(st, s2, L->ev[7]));      // one hand-over for all four weight gradients
+        PSVAE_TRY(linear_bwd_w(s2, w.slog, 4, 0, w.s3, s.P, 0, 1, g.sc_w3, g.sc_b3, s.S, 4, s.P, sc2, scf));
         PSVAE_TRY(linear_bwd_w(s2, w.ds3, s.P, 0, w.s2, s.P2, 0, 1, g.sc_w2, g.sc_b2, s.S, s.P, s.P2, sc2, scf));
         PSVAE_TRY(linear_bwd_w(s2, w.ds2, s.P2, 0, w.s1, s.P2, 0, 1, g.sc_w1, g.sc_b1, s.S, s.P2, s.P2, sc2, scf));
         PSVAE_TRY(linear_bwd_w(s2, w.ds1, s.P2, 0, w.pin, s.P, 0, 1, g.sc_w0, g.sc_b0, s.S, s.P2, s.P, sc2, scf));
@@ -697,7 +737,8 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     }
     const int TH = s.te * s.H;
     if (!dec_only) {
-        if (L) PSVAE_TRY(hand_over(st, s2, L->ev[13]));
+        // (with the fused head d_cond was final before the hand-over above; otherwise it has just been written)
+        if (L && !fused_head) PSVAE_TRY(hand_over(st, s2, L->ev[13]));
         PSVAE_TRY(linear_bwd_w(s2, w.dcond, s.G, 0, w.pooled, TH, 0, 1, g.enc_lin_w, g.enc_lin_b, s.B, s.G, TH, sc2, scf));
         PSVAE_TRY(linear_bwd_x(st, w.dcond, s.G, p.enc_lin_w, w.dpooled, TH, s.B, s.G, TH, nullptr, 0, 0));
     }
@@ -713,7 +754,7 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
         PSVAE_TRY(gine_agg_bwd(st, &top, 1, s.H, s.H, s.H, TH, b.node_graph, s.n, s.H));
     }
     const float* dpool[2] = {w.dpooled, nullptr};
-    if (L && fused_gine && hipStreamWaitEvent(st, L->ev[15], 0) != hipSuccess) return (int)hipGetLastError();
+    if (L && fused_gine && packs_pending && hipStreamWaitEvent(st, L->ev[15], 0) != hipSuccess) return (int)hipGetLastError();
     if (dec_only) {
         PSVAE_TRY(stacks_backward(st, s, w, b, &k[1], 1, &dpool[1], 1, 1));
     } else if (s.te == s.td) {
@@ -793,9 +834,9 @@ extern "C" int psvae_train_step(const psvae_dims* dims, const psvae_params* para
                                 size_t workspace_bytes, const float* loss_weights, float* losses, const float* loss_grads,
                                 const psvae_params* grads, const psvae_adam* opt, void* early_event_1, void* early_event_2,
                                 void* stream) {
-    PSVAE_TRY(psvae_step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream));
+    PSVAE_TRY(step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, true));
     PSVAE_TRY(step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
-                            (hipEvent_t)early_event_1, (hipEvent_t)early_event_2));
+                            (hipEvent_t)early_event_1, (hipEvent_t)early_event_2, true));
     if (opt) {
         if (!opt->params || !opt->grads || !opt->exp_avg || !opt->exp_avg_sq || !opt->partials) return PSVAE_E_NULL;
         PSVAE_TRY(psvae_clip_adam(opt->params, opt->grads, opt->exp_avg, opt->exp_avg_sq, opt->count, opt->partials, opt->max_norm,
