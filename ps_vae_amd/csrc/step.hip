@@ -577,9 +577,14 @@ int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae
     } else {
         PSVAE_TRY(fill_zero(s2, w.mse_row, s.B));   // no property head: its loss reads 0
     }
-    if (L) { PSVAE_TRY(hand_over(s1, st, L->ev[3])); PSVAE_TRY(hand_over(s2, st, L->ev[4])); }
+    // (for_training: no join here.  Backward's kernels take nothing from the six loss values - their upstream gradients
+    //  come from the loss weights and denominators - so the caller's stream goes straight on into backward's link-scorer
+    //  chain, the lanes into backward's piece branch and property head, and backward forms the loss values on a lane
+    //  once it has waited for all three streams' forward work anyway.)
+    if (L && !for_training) { PSVAE_TRY(hand_over(s1, st, L->ev[3])); PSVAE_TRY(hand_over(s2, st, L->ev[4])); }
     // the recurrence's exchange buffer is left zeroed for backward's recurrence, behind the join: nothing waits for it
     PSVAE_TRY(gru_exchange_clear(s1, w.gru_exch, w.gru_exch_bytes, s.B, s.T, s.R));
+    if (for_training) return 0;
     // straight into the caller's buffer (a separate 24-byte copy would be one more dependent launch)
     return losses_finalize(st, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, losses);
 }
@@ -592,14 +597,15 @@ extern "C" int psvae_step_forward(const psvae_dims* dims, const psvae_params* pa
 }
 
 namespace {
-// `after_forward` (psvae_train_step): the forward pass of the same batch was queued by the same library call just before.
-// Its packed weights for backward are in place, and the lanes need no hand-over from the caller's stream to start:
-// what their first kernels read (logits, predictions, the loss gradients the caller prepared before the call) was
-// written on the lanes themselves or before the lanes last waited for the caller's stream.
+// `after_forward` (psvae_train_step): the forward pass of the same batch was queued by the same library call just before,
+// without its closing join and without forming the loss values (`losses_out`: done here).  Its packed weights for
+// backward are in place, and the lanes need no hand-over from the caller's stream to start: what their first kernels
+// read (logits, predictions, the loss gradients the caller prepared before the call) was written on the lanes
+// themselves or before the lanes last waited for the caller's stream.
 int step_backward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch,
                   void* workspace, size_t workspace_bytes, const float* loss_weights,
                   const float* loss_grads, const psvae_params* grads, void* stream, hipEvent_t early1, hipEvent_t early2,
-                  bool after_forward = false) {
+                  bool after_forward = false, float* losses_out = nullptr) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !loss_grads || !grads) return PSVAE_E_NULL;
     const psvae_dims& d = *dims; const psvae_params& p = *params; const psvae_params& g = *grads; const psvae_batch& b = *batch;
@@ -726,6 +732,9 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     else PSVAE_TRY(vae_head_bwd(st, w.mulv, b.eps, dz_a, dz_b, dz_c, gs, b.denoms, w.dmulv, s.B, s.Z));
     // (the weight gradients of these small layers go to lane 2: nothing on the chain waits for them)
     if (L) PSVAE_TRY(hand_over(st, s2, L->ev[12]));
+    // The loss values the forward pass of psvae_train_step left open: by now the caller's stream has waited for lane 1's
+    // piece branch, and lane 2, which has just waited for the caller's stream, holds the property head's rows itself.
+    if (losses_out) PSVAE_TRY(losses_finalize(s2, w.mse_row, s.B, w.rowloss_p, s.BT, w.rowloss_e, s.S, w.klrow, b.denoms, loss_weights, losses_out));
     if (head_adjacent) {
         PSVAE_TRY(linear_bwd_w(s2, w.dmulv, 2 * s.Z, 0, cond, s.G, 0, 1, g.mean_w, g.mean_b, s.B, 2 * s.Z, s.G, sc2, scf));
         if (!fused_head) PSVAE_TRY(linear_bwd_x(st, w.dmulv, 2 * s.Z, p.mean_w, dcond, s.G, s.B, 2 * s.Z, s.G, nullptr, 0, 0));
@@ -836,7 +845,7 @@ extern "C" int psvae_train_step(const psvae_dims* dims, const psvae_params* para
                                 void* stream) {
     PSVAE_TRY(step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, true));
     PSVAE_TRY(step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
-                            (hipEvent_t)early_event_1, (hipEvent_t)early_event_2, true));
+                            (hipEvent_t)early_event_1, (hipEvent_t)early_event_2, true, losses));
     if (opt) {
         if (!opt->params || !opt->grads || !opt->exp_avg || !opt->exp_avg_sq || !opt->partials) return PSVAE_E_NULL;
         PSVAE_TRY(psvae_clip_adam(opt->params, opt->grads, opt->exp_avg, opt->exp_avg_sq, opt->count, opt->partials, opt->max_norm,
