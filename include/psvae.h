@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 6
+#define PSVAE_ABI_VERSION 7
 
 enum {
     PSVAE_OK = 0,
@@ -222,10 +222,17 @@ typedef struct psvae_adam {
     double lr, beta1, beta2, eps, bias1, bias2;       /* as psvae_clip_adam takes them */
     float* grad_norm_out;                             /* device, may be NULL */
 } psvae_adam;
+/* `eps_draw` (or NULL): batch->eps is an unfilled [B, Z] buffer and the call itself draws rsample's epsilon into it -
+ * psvae_normal_rows(seed, draw, first_row, B, Z, batch->eps) - on one of its side streams beside the first kernels,
+ * instead of the caller launching that draw in front of the step. */
+typedef struct psvae_eps_draw {
+    uint64_t seed, draw;     /* as psvae_normal_rows takes them */
+    int64_t first_row;       /* index of the batch's first graph in the global batch */
+} psvae_eps_draw;
 int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
                      size_t workspace_bytes, const float* loss_weights, float* losses, const float* loss_grads,
-                     const psvae_params* grads, const psvae_adam* opt, void* early_event_1, void* early_event_2,
-                     void* stream);
+                     const psvae_params* grads, const psvae_adam* opt, const psvae_eps_draw* eps_draw,
+                     void* early_event_1, void* early_event_2, void* stream);
 /* Creates the current device's two internal side streams now rather than inside the first step call, and checks
  * (with two 100 us probe kernels per pair, timed from the host) that they and `stream` -- the stream the step
  * calls will be given, NULL for the default stream -- run side by side; a side stream that does not is replaced

@@ -77,6 +77,10 @@ class Adam(C.Structure):
                 [('max_norm', f32)] + [(k, C.c_double) for k in ('lr', 'beta1', 'beta2', 'eps', 'bias1', 'bias2')] + [('grad_norm_out', vp)])
 
 
+class EpsDraw(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('draw', C.c_uint64), ('first_row', C.c_int64)]
+
+
 class Batch(C.Structure):
     _fields_ = ([(k, i32) for k in ('B', 'n', 'E', 'E_in', 'S', 'L')] + [(k, vp) for k in BATCH_PTRS] +
                 [('props', vp), ('eps', vp), ('denoms', vp), ('conds', vp), ('d_conds', vp), ('d_z', vp), ('status', vp)])
@@ -117,7 +121,7 @@ def lib():
     L.psvae_step_forward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp]
     L.psvae_step_backward.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp]
     L.psvae_step_backward_signal.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, P(Params), vp, vp, vp]
-    L.psvae_train_step.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp, P(Params), P(Adam), vp, vp, vp]
+    L.psvae_train_step.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, P(f32 * 3), vp, vp, P(Params), P(Adam), P(EpsDraw), vp, vp, vp]
     L.psvae_streams_init.argtypes = [vp]
     L.psvae_encode.argtypes = [P(Dims), P(Params), P(Batch), vp, sz, vp, vp, vp]
     L.psvae_sample_pieces_workspace_bytes.restype = sz
@@ -178,7 +182,7 @@ def lib():
     L.psvae_profile_collect.argtypes = [vp, vp, vp]
     L.psvae_profile_event_overhead_ms.restype = C.c_double
     L.psvae_profile_event_overhead_ms.argtypes = [vp]
-    if L.psvae_abi_version() != 6:
+    if L.psvae_abi_version() != 7:
         raise RuntimeError('libpsvae_hip.so ABI version mismatch; rebuild it')
     _lib = L
     return L

@@ -488,8 +488,11 @@ int backward_packs(hipStream_t on, const psvae_dims& d, const psvae_params& p, c
 
 // `for_training` (psvae_train_step): backward follows inside the same library call, so its packed weights are laid out
 // here as well, beside the forward ones and off every dependent chain.
+// `draw` (psvae_train_step, or null): batch->eps is not filled yet; its rows are drawn here, on lane 1 in front of the
+// weight packs, instead of by a launch of the caller's in front of the whole step.
 int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
-                 size_t workspace_bytes, const float* loss_weights, float* losses, void* stream, bool for_training) {
+                 size_t workspace_bytes, const float* loss_weights, float* losses, void* stream, bool for_training,
+                 const psvae_eps_draw* draw = nullptr) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !losses) return PSVAE_E_NULL;
     if (!aligned16(workspace)) return PSVAE_E_ALIGN;
@@ -514,6 +517,8 @@ int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae
     const bool fused_gine = fused_layers_on() && gine_layer_fused_supported(s.H, s.H, s.H);
     const bool fused_scorer = fused_scorer_fwd_on(s.S, s.H) && scorer_fused_supported(s.H, s.Z, s.H) && pair_head_supported(w.s3, s.P, p.sc_w3, w.ds3, s.P, s.P);
     hipEvent_t packed = nullptr;
+    if (draw && !b.eps) return PSVAE_E_NULL;
+    if (draw) PSVAE_TRY(psvae_normal_rows(draw->seed, draw->draw, draw->first_row, s.B, s.Z, const_cast<float*>(b.eps), L ? s1 : st));
     if (L && (fused_gine || fused_scorer || for_training)) {
         if (fused_gine) {
             const Stack k[2] = {enc_stack(d, p, nullptr, b, w), dec_stack(d, p, nullptr, b, w)};
@@ -526,9 +531,13 @@ int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae
             PSVAE_TRY(fused_pack(s1, pk, cnt));
         }
         if (fused_scorer) PSVAE_TRY(scorer_pack(s1, p.sc_w0, p.sc_w1, p.sc_w2, w.spack, s.H, s.Z));
-        if (fused_gine || fused_scorer) {
+        if (fused_gine || fused_scorer || draw) {
             if (hipEventRecord(L->ev[6], s1) != hipSuccess) return (int)hipGetLastError();
             packed = L->ev[6];
+        }
+        if (draw && !fused_gine) {     // nothing in front of the latent head waits for that event by itself
+            if (hipStreamWaitEvent(st, packed, 0) != hipSuccess) return (int)hipGetLastError();
+            packed = nullptr;
         }
         bool any = false;
         if (for_training) PSVAE_TRY(backward_packs(s1, d, p, b, s, w, &any));    // (reach backward through the join below)
@@ -841,9 +850,9 @@ extern "C" int psvae_step_backward_signal(const psvae_dims* dims, const psvae_pa
 
 extern "C" int psvae_train_step(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
                                 size_t workspace_bytes, const float* loss_weights, float* losses, const float* loss_grads,
-                                const psvae_params* grads, const psvae_adam* opt, void* early_event_1, void* early_event_2,
-                                void* stream) {
-    PSVAE_TRY(step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, true));
+                                const psvae_params* grads, const psvae_adam* opt, const psvae_eps_draw* eps_draw,
+                                void* early_event_1, void* early_event_2, void* stream) {
+    PSVAE_TRY(step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, true, eps_draw));
     PSVAE_TRY(step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
                             (hipEvent_t)early_event_1, (hipEvent_t)early_event_2, true, losses));
     if (opt) {

@@ -412,8 +412,11 @@ class PSVAEModel(nn.Module):
                                'use training_step + backward to accumulate gradients over several batches')
         nb = self._native(batch)
         dev = self._flat.device
-        if eps is None:
-            eps = self.draw_eps(nb.sizes['B'], self._first_graph(nb))
+        draw = None
+        if eps is None:      # the library draws it itself, beside the step's first kernels (the same numbers as draw_eps)
+            eps = torch.empty(nb.sizes['B'], self._dims.latent, dtype=torch.float32, device=dev)
+            draw = _lib.EpsDraw(self.eps_seed, self.eps_draws, int(self._first_graph(nb)))
+            self.eps_draws += 1
         eps = eps.to(dev, torch.float32).contiguous()
         L = _lib.lib()
         bs = nb.struct(eps, self._status_words(dev))
@@ -434,7 +437,7 @@ class PSVAEModel(nn.Module):
         adam = optimizer.fused_struct() if optimizer is not None else None
         _lib.check(L.psvae_train_step(C.byref(self._dims), C.byref(self._params_struct), C.byref(bs), ws.data_ptr(), nbytes,
                                       C.byref(w3), losses.data_ptr(), self._unit[1].data_ptr(), C.byref(self._grads_struct),
-                                      C.byref(adam) if adam is not None else None,
+                                      C.byref(adam) if adam is not None else None, C.byref(draw) if draw is not None else None,
                                       ev[0].cuda_event if ev else None, ev[1].cuda_event if ev else None,
                                       torch.cuda.current_stream(dev).cuda_stream), 'psvae_train_step')
         self._last_ws = (ws, nb)

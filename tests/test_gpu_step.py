@@ -245,6 +245,27 @@ def test_train_step_entry_equals_the_three_calls():
         model.train_step(batch, None, eps=eps[0])
 
 
+def test_train_step_draws_epsilon_itself():
+    """`train_step` without `eps`: the library draws rsample's epsilon inside the call, on a side stream.  Same numbers
+    as `draw_eps` (same seed, same draw counter) handed in by the caller: losses and parameters bit for bit."""
+    from ps_vae_amd import synth
+    d, V, B = O.default_dims(300), 300, 24
+    runs = []
+    for own_draw in (False, True):
+        model, tok, sd = build(d, V)
+        model.eps_seed = 1234
+        opt = model.configure_optimizers()
+        losses = []
+        for i in range(3):
+            _, batch = collate_both(synth.make_molecules(300 + i, 'zinc', V, B), tok, V, 50 + i)
+            eps = None if own_draw else model.draw_eps(B, 0)
+            losses.append(model.train_step(batch, opt, eps=eps).clone())
+            model.global_step += 1
+        assert model.eps_draws == 3
+        runs.append((torch.stack(losses), model.flat_buffers()[0].clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
 def test_two_host_threads_step_on_one_device():
     """Two host threads, each with a model, a stream and batches of its own, run optimiser steps on the same GPU at the
     same time.  The step calls share the device's side streams and events; the library serialises the threads while a
