@@ -1043,6 +1043,10 @@ int gemm_f32(hipStream_t s, const GemmDesc& d) {
 #undef PSVAE_GEMM_LAUNCH
     }
     PSVAE_LAUNCH_CHECK();
+    if (d.slabs_out) {
+        *d.slabs_out = GemmSlabs{slab ? d.scratch : nullptr, slab ? pl.splits : 0, p.slab_stride, p.ld_slab};
+        if (slab) return 0;      // the caller's next kernel sums the slabs
+    }
     if (slab) {
         ReduceP r;
         r.slabs = d.scratch; r.slab_stride = p.slab_stride; r.ld_slab = p.ld_slab;

@@ -380,14 +380,37 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
 // takes every sixteenth output of the 2Z, eight of them per round with all their weight loads in flight at once
 // (lanes split the G inputs, same order of additions as small_linear_fwd_kernel); the results meet in LDS, then
 // the first wave does what vae_head_fwd_kernel does.  Saves a dependent launch.
+// `sl.nz > 0`: the graph's row of cond does not exist yet - the product that makes it (encoder.linear) was split along
+// its reduction and left its slabs behind; the block first adds them up in slab order, adds cond_bias, writes the row
+// to cond (backward reads it) and goes on from its copy in LDS: the slab-sum launch between the two falls away.
 template <int NCH>
 __global__ __launch_bounds__(1024) void latent_head_fwd_kernel(const float* __restrict__ cond, int ldc, const float* __restrict__ w,
                                                                const float* __restrict__ bias, const float* __restrict__ eps,
                                                                float* __restrict__ mulv, float* __restrict__ z,
-                                                               float* __restrict__ klrow, int Z, int G4) {
+                                                               float* __restrict__ klrow, int Z, int G4, const GemmSlabs sl,
+                                                               const float* __restrict__ cond_bias, float* __restrict__ cond_out) {
     __shared__ float sm[1024];
+    __shared__ __attribute__((aligned(16))) float srow[1024];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, N = 2 * Z;
-    const float4* xr = reinterpret_cast<const float4*>(cond + (long long)b * ldc);
+    if (sl.nz > 0) {       // uniform over the launch
+        const int k = threadIdx.x;
+        if (k < G4 * 4) {
+            const float* s = sl.slabs + (long long)b * sl.ld + k;
+            float v = 0.f;
+            int zz = 0;
+            for (; zz + 4 <= sl.nz; zz += 4) {      // the order of gemm_reduce_kernel
+                const float v0 = s[(long long)zz * sl.stride], v1 = s[(long long)(zz + 1) * sl.stride];
+                const float v2 = s[(long long)(zz + 2) * sl.stride], v3 = s[(long long)(zz + 3) * sl.stride];
+                v = (((v + v0) + v1) + v2) + v3;
+            }
+            for (; zz < sl.nz; ++zz) v += s[(long long)zz * sl.stride];
+            v += cond_bias[k];
+            srow[k] = v;
+            cond_out[(long long)b * ldc + k] = v;
+        }
+        __syncthreads();
+    }
+    const float4* xr = sl.nz > 0 ? reinterpret_cast<const float4*>(srow) : reinterpret_cast<const float4*>(cond + (long long)b * ldc);
     float4 xv[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -510,8 +533,21 @@ int latent_head_fwd(hipStream_t s, const float* cond, int ldc, const float* w, c
     if (!latent_head_supported(cond, ldc, w, Z, G)) return PSVAE_E_ALIGN;
     ProfScope prof(s, KC_HEAD, 2.0 * B * 2 * Z * G);
     const int G4 = G / 4;
-    if (G4 <= 128) hipLaunchKernelGGL(latent_head_fwd_kernel<2>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4);
-    else hipLaunchKernelGGL(latent_head_fwd_kernel<4>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4);
+    const GemmSlabs none{nullptr, 0, 0, 0};
+    if (G4 <= 128) hipLaunchKernelGGL(latent_head_fwd_kernel<2>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4, none, nullptr, nullptr);
+    else hipLaunchKernelGGL(latent_head_fwd_kernel<4>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4, none, nullptr, nullptr);
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+// The same with the rows of cond still lying in the slabs of the split product that makes them (see the kernel).
+int latent_head_fwd_slabs(hipStream_t s, const GemmSlabs& sl, const float* cond_bias, float* cond, int ldc, const float* w,
+                          const float* bias, const float* eps, float* mulv, float* z, float* klrow, int B, int Z, int G) {
+    if (B == 0) return 0;
+    if (!latent_head_supported(cond, ldc, w, Z, G) || sl.nz < 1 || !sl.slabs || !cond_bias) return PSVAE_E_ALIGN;
+    ProfScope prof(s, KC_HEAD, 2.0 * B * 2 * Z * G);
+    const int G4 = G / 4;
+    if (G4 <= 128) hipLaunchKernelGGL(latent_head_fwd_kernel<2>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4, sl, cond_bias, cond);
+    else hipLaunchKernelGGL(latent_head_fwd_kernel<4>, dim3(B), dim3(1024), 0, s, cond, ldc, w, bias, eps, mulv, z, klrow, Z, G4, sl, cond_bias, cond);
     PSVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -71,7 +71,12 @@ struct GemmDesc {
     bool sum_segments = false;     // true: all segments add into one C (weight gradients)
     // scratch for split reductions
     float* scratch = nullptr; size_t scratch_floats = 0;
+    // `slabs_out` (plain products only: no mask, ReLU, segments): when the reduction is split, the slab sum is left to
+    // the caller's next kernel - the slabs stay in `scratch`, bias not added, and *slabs_out says where; when it is not
+    // split, C is written as usual and slabs_out->nz = 0.
+    struct GemmSlabs* slabs_out = nullptr;
 };
+struct GemmSlabs { const float* slabs; int nz; long long stride; int ld; };
 int gemm_f32(hipStream_t s, const GemmDesc& d);
 int noalloc_scratch_init();     // resolves the static scratch array of the no-allocation entry point on the current device
 size_t gemm_scratch_floats(int M, int N, int R, int nseg, bool sum_segments);
@@ -201,6 +206,8 @@ int small_linear_bwd_x(hipStream_t s, const float* dy, int lddy, const float* w,
 // [W_mean; W_log_var] (one [2Z, G] matrix) fused with rsample (forward: mulv, z, KL rows) and with its input
 // gradient (backward: d_mulv, d_cond): one launch each instead of two on the step's dependent chain
 bool latent_head_supported(const float* cond, int ldc, const float* w, int Z, int G);
+int latent_head_fwd_slabs(hipStream_t s, const GemmSlabs& sl, const float* cond_bias, float* cond, int ldc, const float* w,
+                          const float* bias, const float* eps, float* mulv, float* z, float* klrow, int B, int Z, int G);
 int latent_head_fwd(hipStream_t s, const float* cond, int ldc, const float* w, const float* bias, const float* eps,
                     float* mulv, float* z, float* klrow, int B, int Z, int G);
 int latent_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float* dz0, const float* dz1, const float* dz2,

@@ -429,14 +429,23 @@ int encoder_to_mulv(hipStream_t st, const psvae_dims& d, const psvae_params& p, 
         PSVAE_TRY(stacks_forward(st, s, w, &k[0], 1, with_rsample, packed));
         if (with_decoder_stack) PSVAE_TRY(stacks_forward(st, s, w, &k[1], 1, with_rsample, packed));
     }
+    const bool adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z;
+    const bool fused_head = with_rsample && adjacent && latent_head_supported(cond, s.G, p.mean_w, s.Z, s.G);
+    GemmSlabs sl{nullptr, 0, 0, 0};
     if (!b.conds) {
         PSVAE_TRY(segment_pool_fwd(st, w.XE + (size_t)s.n * s.H, s.H, (int64_t)s.n * s.H, s.H, b.graph_off, w.pooled, s.te * s.H, s.B, s.te * s.H));
-        PSVAE_TRY(linear_fwd(st, w.pooled, s.te * s.H, p.enc_lin_w, p.enc_lin_b, w.cond, s.G, s.B, s.G, s.te * s.H, 0,
-                             w.scratch, w.scratch_floats));
+        // encoder.linear; in front of the fused head a split reduction leaves its slabs to the head's kernel
+        GemmDesc g;
+        g.A = w.pooled; g.lda = s.te * s.H; g.B = p.enc_lin_w; g.ldb = s.te * s.H; g.C = w.cond; g.ldc = s.G;
+        g.M = s.B; g.N = s.G; g.R = s.te * s.H; g.bias = p.enc_lin_b;
+        g.scratch = w.scratch; g.scratch_floats = w.scratch_floats;
+        if (fused_head && s.G <= 1024) g.slabs_out = &sl;
+        PSVAE_TRY(gemm_f32(st, g));
     }
-    const bool adjacent = p.lvar_w == p.mean_w + (size_t)s.Z * s.G && p.lvar_b == p.mean_b + s.Z;
-    if (with_rsample && adjacent && latent_head_supported(cond, s.G, p.mean_w, s.Z, s.G))    // mulv, z and the KL rows at once
+    if (fused_head) {    // mulv, z and the KL rows at once
+        if (sl.nz > 0) return latent_head_fwd_slabs(st, sl, p.enc_lin_b, w.cond, s.G, p.mean_w, p.mean_b, b.eps, w.mulv, w.z, w.klrow, s.B, s.Z, s.G);
         return latent_head_fwd(st, cond, s.G, p.mean_w, p.mean_b, b.eps, w.mulv, w.z, w.klrow, s.B, s.Z, s.G);
+    }
     if (adjacent) {
         PSVAE_TRY(rows_linear_fwd(st, cond, s.G, p.mean_w, p.mean_b, w.mulv, 2 * s.Z, s.B, 2 * s.Z, s.G, w.scratch, w.scratch_floats));
     } else {
