@@ -211,7 +211,10 @@ int psvae_step_backward_signal(const psvae_dims* dims, const psvae_params* param
  * constant [0,0,0,0,0,1]: the gradient of the weighted total) and, when `opt` is given, psvae_clip_adam over the flat
  * buffers it names.  This is the body of Lightning's training loop for this model (src/pl_models/ps_vae_model.py:76-88
  * `training_step` -> loss.backward() -> src/train.py:47 gradient clipping -> ps_vae_model.py:123-127 Adam) with no
- * host code between the three parts; the enqueued work, and so every result, is that of the three calls.  A
+ * host code between the three parts.  Every result is, bit for bit, that of the three calls; the order in which the
+ * work is queued is not: while the recurrence runs on the multi-CU kernels the call queues forward and backward as one
+ * sequence (no join of the side streams between them, the six loss values written late in backward), which the
+ * separate entry points cannot do because each must leave its results complete on the caller's stream.  A
  * data-parallel caller passes opt = NULL, reduces the gradients and calls psvae_clip_adam itself.  `grads` must
  * describe the same memory as opt->grads (tensor by tensor). */
 typedef struct psvae_adam {

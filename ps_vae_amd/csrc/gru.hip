@@ -539,6 +539,13 @@ static unsigned long long spin_limit() {
     return v < 0 ? SPIN_LIMIT_TICKS : (unsigned long long)v;
 }
 
+// Would a recurrence of B sequences and R units run on the multi-CU kernels (given an exchange buffer)?
+bool gru_multi_cu_selected(int B, int R) {
+    const int forced = opt(OPT_GRU_MULTI_CU);
+    const bool wanted = forced >= 0 ? forced == 1 : (B + ROWS - 1) / ROWS <= COOP_MAX_TILES;
+    return wanted && R % 4 == 0 && R >= 16 && R <= 256;
+}
+
 static bool coop_ok(int R, const void* exch, size_t exch_bytes, int B, int T) {
     // option gru_multi_cu = 0 forces the single-CU kernels (e.g. on a GPU that other processes keep busy: the
     // multi-CU kernels need all workgroups of a sequence tile resident at the same time), 1 the multi-CU ones

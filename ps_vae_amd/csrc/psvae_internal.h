@@ -241,6 +241,7 @@ int link_softmax(hipStream_t s, const float* logits, float* probs, float* conf, 
 // `exch` (gru_exchange_bytes, 16-byte aligned, or NULL) enables the multi-CU recurrence; `status` (device, or
 // NULL): word 0 is set to 1 when a workgroup of that recurrence stopped waiting for its partners
 size_t gru_exchange_bytes(int B, int T, int R);
+bool gru_multi_cu_selected(int B, int R);
 int gru_fwd_stamped(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
                     float* hprev, float* gates, int B, int T, int R, void* exch, size_t exch_bytes, unsigned long long* stamps);
 int gru_fwd(hipStream_t s, const float* gi, const float* h0, const float* whh, const float* bhh, float* hseq,
