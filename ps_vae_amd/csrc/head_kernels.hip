@@ -96,6 +96,50 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(float* __restrict__
     }
 }
 
+// Both of the above in one launch, for a caller that knows the upstream gradient when the losses are formed (the
+// training step as one call): a wave keeps its row in registers (NC values per lane: up to 64 * NC classes), does
+// the forward kernel's arithmetic in the forward kernel's order, then writes the backward kernel's values over the
+// row.  Same bits as the two launches.
+template <int NC>
+__global__ __launch_bounds__(256) void softmax_ce_fwd_bwd_kernel(float* __restrict__ logits, int ld,
+                                                                 const int32_t* __restrict__ target, int tstride, int toffset,
+                                                                 int rpg, int rows, int classes, int ignore_index,
+                                                                 float* __restrict__ row_loss, float* __restrict__ lse_out,
+                                                                 const GScale gscale, int gidx, const float* __restrict__ denoms, int didx) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float* x = logits + (long long)r * ld;
+    float v[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] = lane + 64 * j < classes ? x[lane + 64 * j] : -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) if (lane + 64 * j < classes) mx = fmaxf(mx, v[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) if (lane + 64 * j < classes) s += expf(v[j] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    const int tg = ce_target(target, tstride, toffset, rpg, r);
+    float xt = 0.f;       // the row's value at the target class, from the lane that holds it
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const float t = __shfl(v[j], tg & 63, 64);
+        if ((tg >> 6) == j) xt = t;
+    }
+    if (lane == 0) {
+        lse_out[r] = lse;
+        row_loss[r] = (tg == ignore_index) ? 0.f : lse - xt;
+    }
+    const float scale = gscale_at(gscale, gidx) / denoms[didx];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < classes) x[c] = (tg == ignore_index) ? 0.f : (expf(v[j] - lse) - (c == tg ? 1.f : 0.f)) * scale;
+    }
+}
+
 // Last layer of the link scorer (Linear(P -> 4), src/modules/vae_piece_decoder.py:42-46,110) together with its
 // cross-entropy (:115): with four outputs per row the product is a handful of dot products, not a tile problem.
 // A wave keeps its share of the four weight rows in registers (NCH float4 per row and lane) and walks over rows
@@ -586,6 +630,23 @@ int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* ta
     { ProfScope prof(s, KC_CE, 4.0 * rows * classes);
     hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, ld, target, tstride, toffset,
                        rows_per_group, rows, classes, ignore_index, row_loss, lse);
+    }
+    PSVAE_LAUNCH_CHECK();
+    return 0;
+}
+bool softmax_ce_fused_supported(int classes) { return classes >= 1 && classes <= 512; }
+int softmax_ce_fwd_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
+                       int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse,
+                       GScale gscale, int gidx, const float* denoms, int didx) {
+    if (rows == 0) return 0;
+    if (!softmax_ce_fused_supported(classes)) return PSVAE_E_SHAPE;
+    { ProfScope prof(s, KC_CE, 12.0 * rows * classes);
+    if (classes <= 320)
+        hipLaunchKernelGGL(softmax_ce_fwd_bwd_kernel<5>, dim3((rows + 3) / 4), dim3(256), 0, s, logits_inout, ld, target, tstride, toffset,
+                           rows_per_group, rows, classes, ignore_index, row_loss, lse, gscale, gidx, denoms, didx);
+    else
+        hipLaunchKernelGGL(softmax_ce_fwd_bwd_kernel<8>, dim3((rows + 3) / 4), dim3(256), 0, s, logits_inout, ld, target, tstride, toffset,
+                           rows_per_group, rows, classes, ignore_index, row_loss, lse, gscale, gidx, denoms, didx);
     }
     PSVAE_LAUNCH_CHECK();
     return 0;

@@ -218,6 +218,10 @@ int vae_head_bwd(hipStream_t s, const float* mulv, const float* eps, const float
                  const float* denoms, float* dmulv, int B, int Z);
 int softmax_ce_fwd(hipStream_t s, const float* logits, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse);
+bool softmax_ce_fused_supported(int classes);
+int softmax_ce_fwd_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
+                       int rows_per_group, int rows, int classes, int ignore_index, float* row_loss, float* lse,
+                       GScale gscale, int gidx, const float* denoms, int didx);
 int softmax_ce_bwd(hipStream_t s, float* logits_inout, int ld, const int32_t* target, int tstride, int toffset,
                    int rows_per_group, int rows, int classes, int ignore_index, const float* lse,
                    GScale gscale, int gidx, const float* denoms, int didx);

@@ -501,7 +501,7 @@ int backward_packs(hipStream_t on, const psvae_dims& d, const psvae_params& p, c
 // weight packs, instead of by a launch of the caller's in front of the whole step.
 int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae_batch* batch, void* workspace,
                  size_t workspace_bytes, const float* loss_weights, float* losses, void* stream, bool for_training,
-                 const psvae_eps_draw* draw = nullptr) {
+                 const psvae_eps_draw* draw = nullptr, const float* loss_grads = nullptr) {
     PSVAE_TRY(check_dims(dims, batch));
     if (!params || !workspace || !losses) return PSVAE_E_NULL;
     if (!aligned16(workspace)) return PSVAE_E_ALIGN;
@@ -585,7 +585,14 @@ int step_forward(const psvae_dims* dims, const psvae_params* params, const psvae
     PSVAE_TRY(rows_linear_fwd(s1, w.z, s.Z, p.l2h_w, p.l2h_b, w.h0, s.R, s.B, s.R, s.Z, w.scratch1, scf));
     PSVAE_TRY(gru_fwd(s1, w.gi, w.h0, p.gru_whh, p.gru_bhh, w.hseq, w.hprev, w.gates, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     PSVAE_TRY(linear_fwd(s1, w.hseq, s.R, p.vocab_w, p.vocab_b, w.logits, s.ldl, s.BT, s.V2, s.R, 0, w.scratch1, scf));
-    PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
+    if (for_training && loss_grads && softmax_ce_fused_supported(s.V2)) {
+        // the piece loss's rows and, over the logits, their gradient in one launch (backward then starts at to_vocab)
+        const GScale gs{loss_grads, loss_weights ? loss_weights[0] : 0.f, loss_weights ? loss_weights[1] : 0.f,
+                        loss_weights ? loss_weights[2] : 0.f};
+        PSVAE_TRY(softmax_ce_fwd_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p, gs, 1, b.denoms, 0));
+    } else {
+        PSVAE_TRY(softmax_ce_fwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.rowloss_p, w.lse_p));
+    }
     // lane 2: property head (src/modules/predictor.py:19-21) + squared error rows
     if (!dec_only) {
         PSVAE_TRY(linear_fwd(s2, w.z, s.Z, p.pred_w0, p.pred_b0, w.q1, s.Hp, s.B, s.Hp, s.Z, 1, w.scratch2, scf));
@@ -656,7 +663,8 @@ int step_backward(const psvae_dims* dims, const psvae_params* params, const psva
     // (the recurrence's exchange buffer was zeroed by the forward call, behind its own recurrence, and backward's
     //  recurrence zeroes it again behind itself: no launch in front of the recurrence, no hand-over for it)
     // --- lane 1: piece branch (cross-entropy, to_vocab, GRU, latent_to_rnn_hidden)
-    PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
+    if (!(after_forward && softmax_ce_fused_supported(s.V2)))     // (after_forward: the forward pass left the gradient in place)
+        PSVAE_TRY(softmax_ce_bwd(s1, w.logits, s.ldl, b.pieces, s.L, 1, s.T, s.BT, s.V2, d.pad_idx, w.lse_p, gs, 1, b.denoms, 0));
     PSVAE_TRY(linear_bwd_x(s1, w.logits, s.ldl, p.vocab_w, w.dhseq, s.R, s.BT, s.V2, s.R, nullptr, 0, 0));
     PSVAE_TRY(gru_bwd(s1, w.dhseq, w.hprev, w.gates, p.gru_whh, w.dgi, w.dgh, w.dh0, s.B, s.T, s.R, w.gru_exch, w.gru_exch_bytes, true, b.status));
     if ((long long)s.B * s.Z <= SMALL_LINEAR_OUTPUTS) PSVAE_TRY(small_linear_bwd_x(s1, w.dh0, s.R, p.l2h_w, w.dz_piece, s.Z, s.B, s.R, s.Z));
@@ -876,7 +884,8 @@ extern "C" int psvae_train_step(const psvae_dims* dims, const psvae_params* para
         PSVAE_TRY(step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
                                 (hipEvent_t)early_event_1, (hipEvent_t)early_event_2, false, nullptr));
     } else {
-    PSVAE_TRY(step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, true, eps_draw));
+    if (!loss_grads) return PSVAE_E_NULL;
+    PSVAE_TRY(step_forward(dims, params, batch, workspace, workspace_bytes, loss_weights, losses, stream, true, eps_draw, loss_grads));
     PSVAE_TRY(step_backward(dims, params, batch, workspace, workspace_bytes, loss_weights, loss_grads, grads, stream,
                             (hipEvent_t)early_event_1, (hipEvent_t)early_event_2, true, losses));
     }
